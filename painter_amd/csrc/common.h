@@ -1,0 +1,128 @@
+// Shared device helpers for the gfx950 (CDNA4) kernels of the Painter/SegGPT ViT hot path.
+// wave = 64 lanes everywhere; MFMA 32x32 tiles; LDS tiles are XOR-swizzled 128-byte rows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define DEVI __device__ __forceinline__
+
+// ---------------------------------------------------------------------------------------------
+// element traits: T is the GEMM operand / activation storage type (bf16 "fast" build, float
+// "parity" build).  A 16-byte chunk holds EPC elements; a K tile is always 128 bytes per row.
+template <typename T> struct TT;
+template <> struct TT<float> {
+    static constexpr int EPC = 4;      // elements per 16-B chunk
+    static constexpr int BK = 32;      // K elements per LDS tile row (128 B)
+    static constexpr int KSTEPS = 2;   // 16-element MFMA k-steps per tile
+    static constexpr int SPF = 2;      // 16-B slots per 8-element fragment
+    typedef uint4 Vec4;                // 4 elements
+};
+template <> struct TT<bf16> {
+    static constexpr int EPC = 8;
+    static constexpr int BK = 64;
+    static constexpr int KSTEPS = 4;
+    static constexpr int SPF = 1;
+    typedef uint2 Vec4;
+};
+
+DEVI float to_f(float x) { return x; }
+DEVI float to_f(bf16 x) { return (float)x; }
+template <typename T> DEVI T from_f(float x);
+template <> DEVI float from_f<float>(float x) { return x; }
+template <> DEVI bf16 from_f<bf16>(float x) { return (bf16)x; }   // v_cvt_pk_bf16_f32, RNE
+
+DEVI uint32_t pack_bf16x2(float lo, float hi) {
+    uint16_t a = __builtin_bit_cast(uint16_t, (bf16)lo);
+    uint16_t b = __builtin_bit_cast(uint16_t, (bf16)hi);
+    return (uint32_t)a | ((uint32_t)b << 16);
+}
+DEVI float bf16_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+DEVI float bf16_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// 8-element MFMA operand fragment: lane l holds row (l & 31), contraction slots (l >> 5, t), t = 0..7.
+// Any slot -> contraction-index map is legal as long as the A and the B operand use the same one.
+template <typename T> struct Frag;
+template <> struct Frag<bf16> {
+    bf16x8 v;
+    DEVI void set(uint4 a) { v = __builtin_bit_cast(bf16x8, a); }
+};
+template <> struct Frag<float> {
+    float v[8];
+    DEVI void set(uint4 a, uint4 b) {
+        v[0] = __builtin_bit_cast(float, a.x); v[1] = __builtin_bit_cast(float, a.y);
+        v[2] = __builtin_bit_cast(float, a.z); v[3] = __builtin_bit_cast(float, a.w);
+        v[4] = __builtin_bit_cast(float, b.x); v[5] = __builtin_bit_cast(float, b.y);
+        v[6] = __builtin_bit_cast(float, b.z); v[7] = __builtin_bit_cast(float, b.w);
+    }
+};
+
+// D[i][j] += sum_slots A[i][slot] * B[j][slot];  D layout (all dtypes): lane holds j = lane & 31,
+// i = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5), reg = 0..15.
+DEVI void mma(f32x16& c, const Frag<bf16>& a, const Frag<bf16>& b) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.v, b.v, c, 0, 0, 0);
+}
+DEVI void mma(f32x16& c, const Frag<float>& a, const Frag<float>& b) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a.v[t], b.v[t], c, 0, 0, 0);
+}
+DEVI int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+// ---------------------------------------------------------------------------------------------
+// LDS tile layouts (byte offsets).  Rows are 64/128/256 bytes; the 16-B (or 8-B) unit index is
+// XOR-swizzled with row bits so that every ds_read_b128/b64 lane group and every staging
+// ds_write hits distinct banks (derivation in DESIGN.md "LDS layouts").
+DEVI int lds128(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }   // 8 slots of 16 B
+DEVI int lds256(int row, int slot) { return row * 256 + ((slot ^ (row & 15)) << 4); }         // 16 slots of 16 B
+DEVI int lds64(int row, int gran) { return row * 64 + ((gran ^ ((row >> 2) & 7)) << 3); }     // 8 granules of 8 B
+
+// ---------------------------------------------------------------------------------------------
+DEVI float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+DEVI float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact (erf) GELU and its derivative -- nn.GELU default (Painter/models_painter.py:253)
+DEVI float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+DEVI float gelu_grad_f(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// 4x4 transpose of a register block: in[i] = 4 consecutive elements (along r) of contraction row i;
+// out[j] = the 4 contraction values of element r+j.
+DEVI void transpose4x4(const uint4 (&in)[4], uint4 (&out)[4]) {   // float
+    out[0] = make_uint4(in[0].x, in[1].x, in[2].x, in[3].x);
+    out[1] = make_uint4(in[0].y, in[1].y, in[2].y, in[3].y);
+    out[2] = make_uint4(in[0].z, in[1].z, in[2].z, in[3].z);
+    out[3] = make_uint4(in[0].w, in[1].w, in[2].w, in[3].w);
+}
+DEVI void transpose4x4(const uint2 (&in)[4], uint2 (&out)[4]) {   // bf16 (2 per dword, low half first)
+    out[0] = make_uint2((in[0].x & 0xffffu) | (in[1].x << 16), (in[2].x & 0xffffu) | (in[3].x << 16));
+    out[1] = make_uint2((in[0].x >> 16) | (in[1].x & 0xffff0000u), (in[2].x >> 16) | (in[3].x & 0xffff0000u));
+    out[2] = make_uint2((in[0].y & 0xffffu) | (in[1].y << 16), (in[2].y & 0xffffu) | (in[3].y << 16));
+    out[3] = make_uint2((in[0].y >> 16) | (in[1].y & 0xffff0000u), (in[2].y >> 16) | (in[3].y & 0xffff0000u));
+}
+
+DEVI uint4 zero4() { return make_uint4(0, 0, 0, 0); }
+DEVI void zero_vec(uint4& v) { v = make_uint4(0, 0, 0, 0); }
+DEVI void zero_vec(uint2& v) { v = make_uint2(0, 0); }
+
+// convert 4 floats to a Vec4 of T
+DEVI uint4 cvt4(float a, float b, float c, float d, float*) {
+    return make_uint4(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b),
+                      __builtin_bit_cast(uint32_t, c), __builtin_bit_cast(uint32_t, d));
+}
+DEVI uint2 cvt4(float a, float b, float c, float d, bf16*) { return make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d)); }
+
+#define LAUNCH_CHECK() return (int)hipGetLastError()

@@ -1,0 +1,233 @@
+// nn.Linear forward / dgrad / wgrad entry points on the MFMA engine (gemm_engine.h).
+// Replaces the reference's ATen addmm/mm calls at Painter/models_painter.py:76 (qkv), :87 (proj),
+// timm Mlp fc1/fc2 (:201,:230), :423 (decoder_embed) and their autograd backward (SURVEY.md 8a a4,a9,a10,a13,a17).
+#include "gemm_engine.h"
+#include "../../include/painter_hip.h"
+
+// ------------------------------------------------------------------------------- epilogues
+template <typename OutT> struct EpiBias {   // out[i][j] = acc + bias[j]
+    OutT* out; size_t ldo; const float* bias; int M, N;
+    DEVI void operator()(const f32x16 (&acc)[2][2], int ib, int jb, int lane, int) const {
+        foreach_acc(acc, ib, jb, lane, [&](int i, int j, float v) {
+            if (i < M && j < N) out[(size_t)i * ldo + j] = from_f<OutT>(v + (bias ? bias[j] : 0.f));
+        });
+    }
+};
+template <typename T> struct EpiBiasGelu {   // pre = acc + bias (rounded to T); act = gelu(pre)
+    T* pre; T* act; size_t ld; const float* bias; int M, N;
+    DEVI void operator()(const f32x16 (&acc)[2][2], int ib, int jb, int lane, int) const {
+        foreach_acc(acc, ib, jb, lane, [&](int i, int j, float v) {
+            if (i < M && j < N) {
+                const T p = from_f<T>(v + bias[j]);
+                if (pre) pre[(size_t)i * ld + j] = p;
+                act[(size_t)i * ld + j] = from_f<T>(gelu_f(to_f(p)));
+            }
+        });
+    }
+};
+struct EpiBiasResid {   // out = resid + rowscale[i / rps] * (acc + bias)   (residual add + DropPath factor)
+    float* out; const float* resid; size_t ld; const float* bias; const float* rowscale; int rps; int M, N;
+    DEVI void operator()(const f32x16 (&acc)[2][2], int ib, int jb, int lane, int) const {
+        foreach_acc(acc, ib, jb, lane, [&](int i, int j, float v) {
+            if (i < M && j < N) {
+                const float s = rowscale ? rowscale[i / rps] : 1.f;
+                out[(size_t)i * ld + j] = resid[(size_t)i * ld + j] + s * (v + bias[j]);
+            }
+        });
+    }
+};
+template <typename T> struct EpiDGelu {   // out = acc * gelu'(pre)
+    T* out; const T* pre; size_t ld; int M, N;
+    DEVI void operator()(const f32x16 (&acc)[2][2], int ib, int jb, int lane, int) const {
+        foreach_acc(acc, ib, jb, lane, [&](int i, int j, float v) {
+            if (i < M && j < N) out[(size_t)i * ld + j] = from_f<T>(v * gelu_grad_f(to_f(pre[(size_t)i * ld + j])));
+        });
+    }
+};
+template <typename T> struct EpiPixShuf {   // token-major [b,h,w][p,q,c] -> NHWC image (models_painter.py:424-428)
+    T* out; const float* bias; int Hp, Wp, P, C, M, N;
+    DEVI void operator()(const f32x16 (&acc)[2][2], int ib, int jb, int lane, int) const {
+        const int L = Hp * Wp;
+        foreach_acc(acc, ib, jb, lane, [&](int i, int j, float v) {
+            if (i < M && j < N) {
+                const int b = i / L, l = i % L, h = l / Wp, w = l % Wp;
+                const int c = j % C, pq = j / C, q = pq % P, p = pq / P;
+                const size_t y = (size_t)b * Hp * P + h * P + p, x = (size_t)w * P + q;
+                out[(y * (size_t)(Wp * P) + x) * C + c] = from_f<T>(v + bias[j]);
+            }
+        });
+    }
+};
+struct EpiSlab {   // fp32 partial result of split z (wgrad)
+    float* out; size_t ldo; size_t slab; int M, N;
+    DEVI void operator()(const f32x16 (&acc)[2][2], int ib, int jb, int lane, int z) const {
+        float* o = out + (size_t)z * slab;
+        foreach_acc(acc, ib, jb, lane, [&](int i, int j, float v) {
+            if (i < M && j < N) o[(size_t)i * ldo + j] = v;
+        });
+    }
+};
+
+// ------------------------------------------------------------------------------- reductions
+// out[n] = (accumulate ? out[n] : 0) + sum_z in[z * stride + n]
+__global__ void slab_reduce_kernel(const float* in, float* out, size_t n, int nz, size_t stride, int accumulate) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    if (i + 4 <= n) {
+        float4 s = accumulate ? *reinterpret_cast<const float4*>(out + i) : make_float4(0, 0, 0, 0);
+        for (int z = 0; z < nz; ++z) {
+            const float4 v = *reinterpret_cast<const float4*>(in + (size_t)z * stride + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + i) = s;
+    } else {
+        for (; i < n; ++i) {
+            float s = accumulate ? out[i] : 0.f;
+            for (int z = 0; z < nz; ++z) s += in[(size_t)z * stride + i];
+            out[i] = s;
+        }
+    }
+}
+extern "C" int pa_slab_reduce(const float* in, float* out, int64_t n, int nz, int64_t stride, int accumulate, hipStream_t st) {
+    if (n <= 0) return 0;
+    const int blocks = (int)((n + 1023) / 1024);
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, in, out, (size_t)n, nz, (size_t)stride, accumulate);
+    LAUNCH_CHECK();
+}
+
+// column sums of a [M, N] T matrix (bias gradients): stage 1 partial[chunk][N], stage 2 slab reduce
+template <typename T> __global__ void colsum_kernel(const T* x, size_t ld, int M, int N, int rows_per_chunk, float* part) {
+    // block: 64 column-lanes x 4 row-lanes, each column-lane owns 4 consecutive columns
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c0 = (blockIdx.x * 64 + cl) * 4;
+    const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
+    float s[4] = {0, 0, 0, 0};
+    if (c0 < N) {
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const T* p = x + (size_t)r * ld + c0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += to_f(p[e]);
+        }
+    }
+    __shared__ float red[4][256];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rl][cl * 4 + e] = s[e];
+    __syncthreads();
+    if (rl == 0 && c0 < N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            part[(size_t)blockIdx.y * N + c0 + e] = red[0][cl * 4 + e] + red[1][cl * 4 + e] + red[2][cl * 4 + e] + red[3][cl * 4 + e];
+    }
+}
+extern "C" int64_t pa_colsum_workspace_bytes(int M, int N) {
+    const int chunks = (M + 255) / 256;
+    return (int64_t)chunks * N * sizeof(float);
+}
+extern "C" int pa_colsum(int dtype, const void* x, int64_t ld, int M, int N, float* out, void* workspace, hipStream_t st) {
+    if (N % 4) return (int)hipErrorInvalidValue;
+    const int rpc = 256, chunks = (M + rpc - 1) / rpc;
+    float* part = reinterpret_cast<float*>(workspace);
+    dim3 grid((N / 4 + 63) / 64, chunks);
+    if (dtype == PA_BF16)
+        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (size_t)ld, M, N, rpc, part);
+    else
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (size_t)ld, M, N, rpc, part);
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    return pa_slab_reduce(part, out, N, chunks, N, 0, st);
+}
+
+// ------------------------------------------------------------------------------- linear forward
+template <typename T>
+static int linear_fwd_t(int epi, const T* x, int64_t ldx, const T* w, const float* bias, void* out, void* out2,
+                        int64_t ldo, const float* resid, const float* rowscale, int rps, int M, int N, int K,
+                        hipStream_t st) {
+    OpN<T> A{x, (size_t)ldx, M, 0};
+    OpN<T> B{w, (size_t)K, N, 0};
+    switch (epi) {
+    case PA_EPI_BIAS:
+        return launch_gemm<T, 2, 2>(A, B, EpiBias<T>{(T*)out, (size_t)ldo, bias, M, N}, M, N, K, 1, 1, st);
+    case PA_EPI_BIAS_F32:
+        return launch_gemm<T, 2, 2>(A, B, EpiBias<float>{(float*)out, (size_t)ldo, bias, M, N}, M, N, K, 1, 1, st);
+    case PA_EPI_BIAS_GELU:
+        return launch_gemm<T, 2, 2>(A, B, EpiBiasGelu<T>{(T*)out2, (T*)out, (size_t)ldo, bias, M, N}, M, N, K, 1, 1, st);
+    case PA_EPI_BIAS_RESID:
+        return launch_gemm<T, 2, 2>(A, B, EpiBiasResid{(float*)out, resid, (size_t)ldo, bias, rowscale, rps, M, N}, M, N, K, 1, 1, st);
+    }
+    return (int)hipErrorInvalidValue;
+}
+
+extern "C" int pa_linear_fwd(int dtype, int epilogue, const void* x, int64_t ldx, const void* w, const float* bias,
+                             void* out, void* out2, int64_t ldo, const float* resid, const float* rowscale,
+                             int rows_per_sample, int M, int N, int K, hipStream_t st) {
+    if (K % (dtype == PA_BF16 ? 8 : 4)) return (int)hipErrorInvalidValue;
+    if (dtype == PA_BF16)
+        return linear_fwd_t<bf16>(epilogue, (const bf16*)x, ldx, (const bf16*)w, bias, out, out2, ldo, resid, rowscale, rows_per_sample, M, N, K, st);
+    return linear_fwd_t<float>(epilogue, (const float*)x, ldx, (const float*)w, bias, out, out2, ldo, resid, rowscale, rows_per_sample, M, N, K, st);
+}
+
+template <typename T>
+static int linear_pixshuf_t(const T* x, int64_t ldx, const T* w, const float* bias, T* out, int Bn, int Hp, int Wp,
+                            int P, int C, int K, hipStream_t st) {
+    const int M = Bn * Hp * Wp, N = P * P * C;
+    OpN<T> A{x, (size_t)ldx, M, 0};
+    OpN<T> B{w, (size_t)K, N, 0};
+    return launch_gemm<T, 2, 2>(A, B, EpiPixShuf<T>{out, bias, Hp, Wp, P, C, M, N}, M, N, K, 1, 1, st);
+}
+extern "C" int pa_linear_pixshuf(int dtype, const void* x, int64_t ldx, const void* w, const float* bias, void* out_nhwc,
+                                 int batch, int Hp, int Wp, int P, int C, int K, hipStream_t st) {
+    if (K % 8) return (int)hipErrorInvalidValue;
+    if (dtype == PA_BF16) return linear_pixshuf_t<bf16>((const bf16*)x, ldx, (const bf16*)w, bias, (bf16*)out_nhwc, batch, Hp, Wp, P, C, K, st);
+    return linear_pixshuf_t<float>((const float*)x, ldx, (const float*)w, bias, (float*)out_nhwc, batch, Hp, Wp, P, C, K, st);
+}
+
+// ------------------------------------------------------------------------------- linear backward
+// dX[M,K] = dY[M,N] . W[N,K]      (contraction over N; W is contraction-major -> OpT)
+template <typename T>
+static int linear_dgrad_t(const T* dy, int64_t lddy, const T* w, const T* pre, T* dx, int64_t lddx, int M, int N, int K,
+                          hipStream_t st) {
+    OpN<T> A{dy, (size_t)lddy, M, 0};
+    OpT<T> B{w, (size_t)K, K, 0};
+    if (pre) return launch_gemm<T, 2, 2>(A, B, EpiDGelu<T>{dx, pre, (size_t)lddx, M, K}, M, K, N, 1, 1, st);
+    return launch_gemm<T, 2, 2>(A, B, EpiBias<T>{dx, (size_t)lddx, nullptr, M, K}, M, K, N, 1, 1, st);
+}
+extern "C" int pa_linear_dgrad(int dtype, const void* dy, int64_t lddy, const void* w, const void* pre_for_dgelu,
+                               void* dx, int64_t lddx, int M, int N, int K, hipStream_t st) {
+    if (N % 8 || K % 4) return (int)hipErrorInvalidValue;
+    if (dtype == PA_BF16) return linear_dgrad_t<bf16>((const bf16*)dy, lddy, (const bf16*)w, (const bf16*)pre_for_dgelu, (bf16*)dx, lddx, M, N, K, st);
+    return linear_dgrad_t<float>((const float*)dy, lddy, (const float*)w, (const float*)pre_for_dgelu, (float*)dx, lddx, M, N, K, st);
+}
+
+// dW[N,K] = dY[M,N]^T . X[M,K]    (contraction over M; both operands contraction-major), split-K + reduce
+static int wgrad_splits(int M, int N, int K, int bk) {
+    const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+    const int nku = (M + bk - 1) / bk;
+    int s = (640 + tiles - 1) / tiles;        // aim for >= 2.5 workgroups per CU
+    if (s > nku) s = nku;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    return s;
+}
+extern "C" int64_t pa_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K) {
+    const int s = wgrad_splits(M, N, K, dtype == PA_BF16 ? 64 : 32);
+    return s > 1 ? (int64_t)s * N * K * sizeof(float) : 0;
+}
+template <typename T>
+static int linear_wgrad_t(const T* dy, int64_t lddy, const T* x, int64_t ldx, float* dw, float* ws, int M, int N, int K,
+                          hipStream_t st) {
+    OpT<T> A{dy, (size_t)lddy, N, 0};
+    OpT<T> B{x, (size_t)ldx, K, 0};
+    const int s = wgrad_splits(M, N, K, TT<T>::BK);
+    if (s == 1) return launch_gemm<T, 2, 2>(A, B, EpiSlab{dw, (size_t)K, 0, N, K}, N, K, M, 1, 1, st);
+    int e = launch_gemm<T, 2, 2>(A, B, EpiSlab{ws, (size_t)K, (size_t)N * K, N, K}, N, K, M, s, 1, st);
+    if (e) return e;
+    return pa_slab_reduce(ws, dw, (int64_t)N * K, s, (int64_t)N * K, 0, st);
+}
+extern "C" int pa_linear_wgrad(int dtype, const void* dy, int64_t lddy, const void* x, int64_t ldx, float* dw,
+                               void* workspace, int M, int N, int K, hipStream_t st) {
+    if (N % 4 || K % 4) return (int)hipErrorInvalidValue;
+    if (dtype == PA_BF16) return linear_wgrad_t<bf16>((const bf16*)dy, lddy, (const bf16*)x, ldx, dw, (float*)workspace, M, N, K, st);
+    return linear_wgrad_t<float>((const float*)dy, lddy, (const float*)x, ldx, dw, (float*)workspace, M, N, K, st);
+}
+
+extern "C" int pa_abi_version(void) { return 1; }

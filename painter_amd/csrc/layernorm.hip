@@ -1,0 +1,196 @@
+// LayerNorm forward / backward over the channel dim of the fp32 residual stream.
+// Replaces aten::native_layer_norm(_backward) at Painter/models_painter.py:218,230 (norm1/norm2,
+// eps 1e-6 via partial(nn.LayerNorm) :480) and the shared tap norm :416-417.
+// HBM-bound: one wave per row, 16-byte loads, two-pass variance in registers, shuffle reductions.
+#include "common.h"
+#include "../../include/painter_hip.h"
+
+template <typename T> DEVI void store4(T* p, float a, float b, float c, float d);
+template <> DEVI void store4<float>(float* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+template <> DEVI void store4<bf16>(bf16* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+DEVI float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+DEVI float4 load4(const bf16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
+}
+
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, size_t ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, T* __restrict__ y, size_t ldy,
+                                                     float* __restrict__ mean, float* __restrict__ rstd, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= R) return;
+    const float* xr = x + (size_t)row * ldx;
+    float4 v[NI];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane * 4 + 256 * i;
+        v[i] = (c < D) ? load4(xr + c) : make_float4(0, 0, 0, 0);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    const float mu = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < D) {
+            const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, d = v[i].w - mu;
+            q += (a * a + b * b) + (cc * cc + d * d);
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)D + eps);
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+    T* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < D) {
+            const float4 g = load4(gamma + c), b = load4(beta + c);
+            store4<T>(yr + c, (v[i].x - mu) * rs * g.x + b.x, (v[i].y - mu) * rs * g.y + b.y,
+                      (v[i].z - mu) * rs * g.z + b.z, (v[i].w - mu) * rs * g.w + b.w);
+        }
+    }
+}
+
+// dx_out = (dres ? dres : 0) + LNbwd(dy);  optional T copy dxT = rowscale[row / rps] * dx_out;
+// per-workgroup partial dgamma / dbeta -> part[block][2][D]
+template <typename T, int NI>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, size_t lddy, const float* __restrict__ x, size_t ldx,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     const float* __restrict__ gamma, const float* dres, float* dx, size_t lddx,
+                                                     T* dxT, size_t lddxT, const float* __restrict__ rowscale, int rps,
+                                                     float* __restrict__ part, int R, int D) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 g[NI], ag[NI], ab[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane * 4 + 256 * i;
+        g[i] = (c < D) ? load4(gamma + c) : make_float4(0, 0, 0, 0);
+        ag[i] = make_float4(0, 0, 0, 0);
+        ab[i] = make_float4(0, 0, 0, 0);
+    }
+    for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const T* dyr = dy + (size_t)row * lddy;
+        const float* xr = x + (size_t)row * ldx;
+        float4 d[NI], xh[NI];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < D) {
+                d[i] = load4(dyr + c);
+                const float4 xv = load4(xr + c);
+                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
+                ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
+                d[i].x *= g[i].x; d[i].y *= g[i].y; d[i].z *= g[i].z; d[i].w *= g[i].w;      // dxhat
+                s1 += (d[i].x + d[i].y) + (d[i].z + d[i].w);
+                s2 += (d[i].x * xh[i].x + d[i].y * xh[i].y) + (d[i].z * xh[i].z + d[i].w * xh[i].w);
+            }
+        }
+        const float c1 = wave_sum(s1) / (float)D, c2 = wave_sum(s2) / (float)D;
+        const float sc = (dxT && rowscale) ? rowscale[row / rps] : 1.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < D) {
+                float4 o = make_float4(rs * (d[i].x - c1 - xh[i].x * c2), rs * (d[i].y - c1 - xh[i].y * c2),
+                                       rs * (d[i].z - c1 - xh[i].z * c2), rs * (d[i].w - c1 - xh[i].w * c2));
+                if (dres) {
+                    const float4 r = load4(dres + (size_t)row * lddx + c);
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                *reinterpret_cast<float4*>(dx + (size_t)row * lddx + c) = o;
+                if (dxT) store4<T>(dxT + (size_t)row * lddxT + c, o.x * sc, o.y * sc, o.z * sc, o.w * sc);
+            }
+        }
+    }
+    // block reduce of the 4 waves' partial dgamma / dbeta
+    extern __shared__ float red[];   // [4][2][D]
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < D) {
+            *reinterpret_cast<float4*>(red + (size_t)(wave * 2 + 0) * D + c) = ag[i];
+            *reinterpret_cast<float4*>(red + (size_t)(wave * 2 + 1) * D + c) = ab[i];
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * D; idx += 256) {
+        const float s = red[idx] + red[2 * D + idx] + red[4 * D + idx] + red[6 * D + idx];
+        part[(size_t)blockIdx.x * 2 * D + idx] = s;
+    }
+}
+
+extern "C" int pa_slab_reduce(const float* in, float* out, int64_t n, int nz, int64_t stride, int accumulate, hipStream_t st);
+
+template <typename T>
+static int ln_fwd_t(const float* x, int64_t ldx, const float* g, const float* b, float eps, T* y, int64_t ldy, float* mean,
+                    float* rstd, int R, int D, hipStream_t st) {
+    const int ni = (D + 255) / 256;
+    dim3 grid((R + 3) / 4), blk(256);
+#define LN_FWD(NI) hipLaunchKernelGGL((ln_fwd_kernel<T, NI>), grid, blk, 0, st, x, (size_t)ldx, g, b, eps, y, (size_t)ldy, mean, rstd, R, D)
+    if (ni <= 1) LN_FWD(1);
+    else if (ni <= 2) LN_FWD(2);
+    else if (ni <= 4) LN_FWD(4);
+    else if (ni <= 5) LN_FWD(5);
+    else if (ni <= 8) LN_FWD(8);
+    else return (int)hipErrorInvalidValue;
+#undef LN_FWD
+    LAUNCH_CHECK();
+}
+extern "C" int pa_layernorm_fwd(int dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,
+                                void* y, int64_t ldy, float* mean, float* rstd, int R, int D, hipStream_t st) {
+    if (D % 4 || ldx % 4 || ldy % 4) return (int)hipErrorInvalidValue;
+    if (dtype == PA_BF16) return ln_fwd_t<bf16>(x, ldx, gamma, beta, eps, (bf16*)y, ldy, mean, rstd, R, D, st);
+    return ln_fwd_t<float>(x, ldx, gamma, beta, eps, (float*)y, ldy, mean, rstd, R, D, st);
+}
+
+static int ln_bwd_blocks(int R) {
+    int b = (R + 3) / 4;
+    return b > 512 ? 512 : b;
+}
+extern "C" int64_t pa_layernorm_bwd_workspace_bytes(int R, int D) { return (int64_t)ln_bwd_blocks(R) * 2 * D * sizeof(float); }
+
+template <typename T>
+static int ln_bwd_t(const T* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean, const float* rstd,
+                    const float* gamma, const float* dres, float* dx, int64_t lddx, T* dxT, int64_t lddxT,
+                    const float* rowscale, int rps, float* dgamma_dbeta, float* ws, int R, int D, hipStream_t st) {
+    const int ni = (D + 255) / 256;
+    const int nb = ln_bwd_blocks(R);
+    dim3 grid(nb), blk(256);
+    const size_t sm = (size_t)8 * D * sizeof(float);
+#define LN_BWD(NI) hipLaunchKernelGGL((ln_bwd_kernel<T, NI>), grid, blk, sm, st, dy, (size_t)lddy, x, (size_t)ldx, mean, rstd, gamma, dres, dx, (size_t)lddx, dxT, (size_t)lddxT, rowscale, rps, ws, R, D)
+    if (ni <= 1) LN_BWD(1);
+    else if (ni <= 2) LN_BWD(2);
+    else if (ni <= 4) LN_BWD(4);
+    else if (ni <= 5) LN_BWD(5);
+    else if (ni <= 8) LN_BWD(8);
+    else return (int)hipErrorInvalidValue;
+#undef LN_BWD
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    return pa_slab_reduce(ws, dgamma_dbeta, 2 * D, nb, 2 * D, 0, st);
+}
+// dgamma_dbeta: [2, D] fp32 (dgamma then dbeta), overwritten.
+extern "C" int pa_layernorm_bwd(int dtype, const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
+                                const float* rstd, const float* gamma, const float* dres, float* dx, int64_t lddx,
+                                void* dxT, int64_t lddxT, const float* rowscale, int rows_per_sample,
+                                float* dgamma_dbeta, void* workspace, int R, int D, hipStream_t st) {
+    if (D % 4 || lddy % 4 || ldx % 4 || lddx % 4 || lddxT % 4) return (int)hipErrorInvalidValue;
+    if (dtype == PA_BF16)
+        return ln_bwd_t<bf16>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres, dx, lddx, (bf16*)dxT, lddxT, rowscale,
+                              rows_per_sample, dgamma_dbeta, (float*)workspace, R, D, st);
+    return ln_bwd_t<float>((const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres, dx, lddx, (float*)dxT, lddxT, rowscale,
+                           rows_per_sample, dgamma_dbeta, (float*)workspace, R, D, st);
+}

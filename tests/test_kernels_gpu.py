@@ -1,0 +1,176 @@
+"""GPU parity tests of the individual HIP kernels (through the C ABI) against plain PyTorch fp32/fp64
+references of the same op.  fp32 build: gate 1e-4..1e-3 (exact-fp32 MFMA); bf16 build: gate relative to the
+bf16 rounding of the operands (stated per test)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from painter_amd import ops
+    from painter_amd._lib import EPI_BIAS, EPI_BIAS_F32, EPI_BIAS_GELU, EPI_BIAS_RESID
+
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def gen(shape, seed, scale=1.0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(200, 192, 128), (64, 64, 72), (37 * 8, 384, 72 * 8), (12544, 1024, 1024)])
+def test_linear_fwd_epilogues(T, M, N, K):
+    x = gen((M, K), 1, 1.0, T)
+    w = gen((N, K), 2, 0.05, T)     # asymmetric, non-square: catches transposes
+    b = gen((N,), 3)
+    ref = x.float() @ w.float().t() + b
+    y = ops.linear_fwd(x, w, b, EPI_BIAS)
+    assert y.dtype == T
+    assert relerr(y.float(), ref) < TOL[T]
+    y32 = ops.linear_fwd(x, w, b, EPI_BIAS_F32)
+    assert relerr(y32, ref) < (2e-5 if T == torch.float32 else 1e-2)
+    act, pre = ops.linear_gelu(x, w, b)
+    assert relerr(pre.float(), ref) < TOL[T]
+    assert relerr(act.float(), torch.nn.functional.gelu(pre.float())) < TOL[T]
+    resid = gen((M, N), 4)
+    rps = 8
+    rowscale = gen(((M + rps - 1) // rps,), 5).abs() + 0.5
+    out = ops.linear_fwd(x, w, b, EPI_BIAS_RESID, resid=resid, rowscale=rowscale, rows_per_sample=rps)
+    rs = rowscale.repeat_interleave(rps)[:M, None]
+    assert relerr(out, resid + rs * ref) < (2e-5 if T == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(200, 192, 128), (96, 64, 72), (12544, 1024, 4096)])
+def test_linear_backward(T, M, N, K):
+    dy = gen((M, N), 1, 1.0, T)
+    w = gen((N, K), 2, 0.05, T)
+    x = gen((M, K), 3, 1.0, T)
+    pre = gen((M, K), 4, 1.0, T)
+    dx_ref = dy.float() @ w.float()
+    dx = ops.linear_dgrad(dy, w)
+    assert relerr(dx.float(), dx_ref) < TOL[T]
+    xg = pre.float().clone().requires_grad_(True)
+    torch.nn.functional.gelu(xg).backward(torch.ones_like(xg))
+    dxg = ops.linear_dgrad(dy, w, pre=pre)
+    assert relerr(dxg.float(), dx_ref * xg.grad) < TOL[T]
+    dw = ops.linear_wgrad(dy, x)
+    dw_ref = dy.double().t() @ x.double()
+    assert dw.dtype == torch.float32
+    assert relerr(dw, dw_ref) < (2e-5 if T == torch.float32 else 1e-4)     # inputs are exact in T; fp32 accumulate
+    db = ops.colsum(dy)
+    assert relerr(db, dy.double().sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+def test_linear_strided_views_and_pixshuf(T):
+    """Column-slice inputs (tap concat buffer) and the decoder pixel-shuffle epilogue (models_painter.py:424-428)."""
+    B, Hp, Wp, P, C, K = 2, 8, 4, 16, 64, 256
+    M = B * Hp * Wp
+    big = gen((M, 2 * K), 1, 1.0, T)
+    x = big[:, K:]
+    w = gen((P * P * C, K), 2, 0.05, T)
+    b = gen((P * P * C,), 3)
+    out = ops.linear_pixshuf(x, w, b, B, Hp, Wp, P, C)
+    ref = (x.float() @ w.float().t() + b).reshape(B, Hp, Wp, P, P, C)
+    ref = torch.einsum("nhwpqc->nchpwq", ref).reshape(B, C, Hp * P, Wp * P).permute(0, 2, 3, 1)
+    assert relerr(out.float(), ref) < TOL[T]
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R,D", [(64, 128), (1000, 1024), (25088, 1024), (33, 1280)])
+def test_layernorm_fwd_bwd(T, R, D):
+    x = gen((R, D), 1, 2.0) + 0.3
+    gamma = 1 + gen((D,), 2, 0.1)
+    beta = gen((D,), 3, 0.1)
+    xr = x.double().clone().requires_grad_(True)
+    gr, br = gamma.double().clone().requires_grad_(True), beta.double().clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), gr, br, 1e-6)
+    y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, 1e-6, T)
+    assert relerr(y.float(), yr.detach()) < (1e-5 if T == torch.float32 else 1e-2)
+    assert relerr(mean, x.double().mean(1)) < 1e-5
+    dy = gen((R, D), 4, 1.0, T)
+    yr.backward(dy.double())
+    dres = gen((R, D), 5)
+    rps = 8
+    rowscale = gen(((R + rps - 1) // rps,), 6).abs() + 0.5
+    dxT = torch.empty((R, D), dtype=T, device=DEV)
+    dx, gb = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres=dres, dxT=dxT, rowscale=rowscale, rows_per_sample=rps)
+    ref = dres.double() + xr.grad
+    assert relerr(dx, ref) < 2e-5
+    assert relerr(dxT.float(), ref * rowscale.repeat_interleave(rps)[:R, None].double()) < TOL[T]
+    assert relerr(gb[0], gr.grad) < 1e-4
+    assert relerr(gb[1], br.grad) < 1e-4
+    # in-place accumulate form (dres aliases dx), no T copy
+    dx2 = dres.clone()
+    ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres=dx2, dx=dx2)
+    assert relerr(dx2, ref) < 2e-5
+
+
+def attn_reference(qkv, rel_h, rel_w, B, L, H, Hp, Wp, scale):
+    """Painter/models_painter.py:76-86 + util/vitdet_utils.py:96-125 in fp64."""
+    D = H * 64
+    q, k, v = qkv.double().reshape(B, L, 3, H, 64).permute(2, 0, 3, 1, 4).reshape(3, B * H, L, 64).unbind(0)
+    attn = (q * scale) @ k.transpose(-2, -1)
+    ih = (torch.arange(Hp)[:, None] - torch.arange(Hp)[None, :] + Hp - 1).to(qkv.device)
+    iw = (torch.arange(Wp)[:, None] - torch.arange(Wp)[None, :] + Wp - 1).to(qkv.device)
+    Rh, Rw = rel_h.double()[ih], rel_w.double()[iw]
+    rq = q.reshape(B * H, Hp, Wp, 64)
+    bh = torch.einsum("bhwc,hkc->bhwk", rq, Rh)
+    bw = torch.einsum("bhwc,wkc->bhwk", rq, Rw)
+    attn = (attn.view(B * H, Hp, Wp, Hp, Wp) + bh[..., :, None] + bw[..., None, :]).view(B * H, L, L)
+    lse = torch.logsumexp(attn, dim=-1)
+    o = attn.softmax(-1) @ v
+    return o.view(B, H, L, 64).permute(0, 2, 1, 3).reshape(B * L, D), lse
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Hp,Wp", [(1, 2, 8, 4), (2, 2, 56, 28), (1, 1, 16, 8)])
+def test_attn_fwd(T, B, H, Hp, Wp):
+    L = Hp * Wp
+    qkv = gen((B * L, 3 * H * 64), 1, 1.0, T)
+    rel_h = gen((2 * Hp - 1, 64), 2, 0.2)
+    rel_w = gen((2 * Wp - 1, 64), 3, 0.2)
+    rcat = ops.relpos_pack(rel_h, rel_w, Hp, Wp, T)
+    assert relerr(rcat[: 2 * Hp - 1].float(), rel_h) < (1e-7 if T == torch.float32 else 1e-2)
+    out, lse = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125)
+    ref, lse_ref = attn_reference(qkv, rcat[: 2 * Hp - 1], rcat[2 * Hp - 1: 2 * Hp + 2 * Wp - 2], B, L, H, Hp, Wp, 0.125)
+    e_o, e_l = relerr(out.float(), ref), relerr(lse, lse_ref)
+    assert e_l < (1e-5 if T == torch.float32 else 2e-3), (e_o, e_l)
+    assert e_o < (2e-5 if T == torch.float32 else 2e-2), (e_o, e_l)
+
+
+def test_attn_fwd_spiked_key_online_softmax():
+    """Force large running-max jumps late in the key stream (rule: a data-dependent rescale needs its own test)."""
+    B, H, Hp, Wp = 1, 1, 16, 8
+    L = Hp * Wp
+    qkv = gen((B * L, 3 * 64), 7, 0.5)
+    qkv[5, 0:64] = 3.0            # q row 5
+    qkv[100, 64:128] = 3.0        # k row 100 -> logit spike 0.125*9*64 = 72 at tile 3
+    rel = torch.zeros((2 * Hp - 1, 64), device=DEV), torch.zeros((2 * Wp - 1, 64), device=DEV)
+    rcat = ops.relpos_pack(rel[0], rel[1], Hp, Wp, torch.float32)
+    out, lse = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125)
+    ref, lse_ref = attn_reference(qkv, rel[0], rel[1], B, L, H, Hp, Wp, 0.125)
+    assert relerr(out, ref) < 2e-5 and relerr(lse, lse_ref) < 1e-5
+
+
+def test_determinism_same_input_bit_identical():
+    x = gen((777, 1024), 1, 1.0, torch.bfloat16)
+    w = gen((1024, 1024), 2, 0.05, torch.bfloat16)
+    dy = gen((777, 1024), 3, 1.0, torch.bfloat16)
+    a = ops.linear_wgrad(dy, x).clone()
+    b = ops.linear_wgrad(dy, x).clone()
+    assert torch.equal(a, b)
+    c, d = ops.linear_dgrad(dy, w).clone(), ops.linear_dgrad(dy, w).clone()
+    assert torch.equal(c, d)
