@@ -79,6 +79,88 @@ int pa_relpos_pack(int dtype, const float* rel_pos_h, const float* rel_pos_w, vo
 int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse, int batch,
                 int L, int heads, int Hp, int Wp, float scale, hipStream_t stream);
 
+/* autograd of pa_attn_fwd (no reference source: torch autograd of the lines above).
+ *   delta  : f32 [batch*heads, L] = rowsum(dO o O)                      (pa_attn_bwd_delta)
+ *   dqkv   : T, same layout as qkv (dq | dk | dv)
+ *   dG     : T [batch*L, heads*NRP] r-space bias gradient, consumed by pa_attn_bwd_relpos
+ *   aux    : scratch of pa_attn_bwd_aux_bytes()
+ *   rcatT  : T [64, NRP] from pa_relpos_pack_t
+ *   drcat  : f32 [NRP, 64] = [d rel_pos_h ; d rel_pos_w ; 0], overwritten */
+int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcatT, int Hp, int Wp,
+                     hipStream_t stream);
+int pa_attn_bwd_delta(int dtype, const void* out, int64_t ldo, const void* dout, int64_t lddo, float* delta, int batch,
+                      int L, int heads, hipStream_t stream);
+int64_t pa_attn_bwd_aux_bytes(int batch, int L, int heads, int Hp, int Wp);
+int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, const void* rcatT, const void* dout,
+                int64_t lddo, const float* lse, const float* delta, void* dqkv, void* dG, void* aux, int batch, int L,
+                int heads, int Hp, int Wp, float scale, hipStream_t stream);
+int64_t pa_attn_bwd_relpos_workspace_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp);
+int pa_attn_bwd_relpos(int dtype, const void* dG, const void* qkv, int64_t ldq, float* drcat, void* workspace,
+                       int batch, int L, int heads, int Hp, int Wp, hipStream_t stream);
+
+/* ---- PatchEmbed (Conv2d k=P s=P as an im2col GEMM) + token assembly: util/vitdet_utils.py:182-186,
+ *      models_painter.py:387-409 (mask token, segment tokens, abs pos), models_seggpt.py:415-420 (type tokens) ----
+ * imgs/tgts: f32 NCHW [B,3,Hp*P,Wp*P]; w: T [D, 3*P*P]; pos: f32 [L, D] from pa_pos_fwd; mask: bool bytes [B or 1, L];
+ * type_cls/type_ins/seg_type: SegGPT only (NULL otherwise), seg_type f32 [B];
+ * tokens: f32 [2*B*L, D] = cat(x stream, y stream) on the batch axis (models_painter.py:409). */
+int pa_patch_embed_fwd(int dtype, const float* imgs, const float* tgts, const void* w, const float* bias,
+                       const float* mask_token, const float* seg_x, const float* seg_y, const float* pos,
+                       const unsigned char* mask, int mask_batch_stride, const float* type_cls, const float* type_ins,
+                       const float* seg_type, float* tokens, int batch, int Hp, int Wp, int P, int D, hipStream_t stream);
+int64_t pa_patch_embed_wgrad_workspace_bytes(int D, int P);
+int pa_patch_embed_wgrad(int dtype, const void* dpe /*T [2BL, D]*/, const float* imgs, const float* tgts,
+                         float* dw /*f32 [D, 3*P*P]*/, void* workspace, int batch, int Hp, int Wp, int P, int D,
+                         hipStream_t stream);
+/* get_abs_pos (util/vitdet_utils.py:128-157) as the constant bicubic operator M [L, S] (host-built, f32);
+ * pe/dpe point at pos_embed[0, skip_cls:, :] ([S, D]). */
+int pa_pos_fwd(const float* M, const float* pe, float* pos, int L, int S, int D, hipStream_t stream);
+int pa_pos_bwd(const float* M, const float* gx, const float* gy, float* dpe, int L, int S, int D, hipStream_t stream);
+/* backward of the token assembly: dpe T [2BL, D]; sums f32 [3, L, D] = sum_b dx | sum_b dy | sum_b w*dy */
+int pa_tokens_bwd(int dtype, const float* dx0, const unsigned char* mask, int mask_batch_stride, void* dpe, float* sums,
+                  int batch, int L, int D, hipStream_t stream);
+
+/* ---- x = (x[:B] + x[B:]) * 0.5 after block merge_idx (models_painter.py:414-415) and its backward ---- */
+int pa_merge_fwd(const float* x, float* out, int64_t n_out, hipStream_t stream);
+int pa_merge_bwd(int dtype, const float* dmerged, float* dx, void* dxT, const float* rowscale, int rows_per_sample,
+                 int64_t rows_half, int D, hipStream_t stream);
+int pa_scale_cast(int dtype, const float* in, void* out, const float* rowscale, int rows_per_sample, int64_t rows, int D,
+                  hipStream_t stream);
+int pa_cast_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
+/* SegGPT cross-prompt feature ensemble + residual (models_seggpt.py:220-232): x1 = x0 + ens(a), groups of `group` samples */
+int pa_ensemble_resid(const float* x0, const float* a, float* x1, int batch, int group, int L, int D, hipStream_t stream);
+
+/* ---- decoder_pred: Conv3x3(64->64) -> LayerNorm2D -> GELU -> Conv1x1(64->3), one fused kernel
+ *      (models_painter.py:328-333,:430; util/vitdet_utils.py:204-209) and its backward pieces ---- */
+int pa_conv3x3_pack(int dtype, const float* w3 /*[64,64,3,3]*/, void* w3r /*T [64][9][64]*/, void* wf /*T [64][9][64]*/,
+                    hipStream_t stream);
+int pa_decoder_tail_fwd(int dtype, const void* x_nhwc, const void* w3r, const float* b3, const float* ln_gamma,
+                        const float* ln_beta, const float* w1 /*[3,64]*/, const float* b1, void* y3 /*T NHWC or NULL*/,
+                        float* pred /*f32 NCHW [B,3,Hi,Wi]*/, int batch, int Hi, int Wi, float eps, hipStream_t stream);
+int64_t pa_decoder_tail_bwd_workspace_bytes(int batch, int Hi, int Wi);
+/* grads: f32 [324] = dgamma[64] | dbeta[64] | dW1[3*64] | db1[3] | pad; dy3: T NHWC gradient of the conv3x3 output */
+int pa_decoder_tail_bwd_pointwise(int dtype, const float* dpred, const void* y3, const float* ln_gamma,
+                                  const float* ln_beta, const float* w1, void* dy3, float* grads, void* workspace,
+                                  int batch, int Hi, int Wi, float eps, hipStream_t stream);
+/* dE: T [B*Hp*Wp, P*P*64] = gradient w.r.t. decoder_embed's output (pixel shuffle inverted in the epilogue) */
+int pa_conv3x3_dgrad_unshuffle(int dtype, const void* dy3, const void* wf, void* dE, int batch, int Hp, int Wp, int P,
+                               hipStream_t stream);
+int64_t pa_conv3x3_wgrad_workspace_bytes(int batch, int Hi, int Wi);
+int pa_conv3x3_wgrad(int dtype, const void* dy3, const void* x_nhwc, float* dw /*f32 [64,64,3,3]*/, void* workspace,
+                     int batch, int Hi, int Wi, hipStream_t stream);
+
+/* ---- forward_loss (models_painter.py:433-462; SegGPT models_seggpt.py:448-469) ----
+ * out: f32 [2] = {loss, denominator}.  ignore_rule = 1 (Painter): samples whose unmasked de-normalised target sums
+ * below 300 get valid := 0 IN PLACE (models_painter.py:444-448).  kind: 0 smoothl1(beta) 1 l1 2 l2 3 l1l2. */
+int64_t pa_loss_workspace_bytes(int batch, int Hi, int Wi);
+int pa_loss_fwd(const float* pred, const float* tgts, float* valid, const unsigned char* mask, int mask_batch_stride,
+                float* out, void* workspace, int batch, int Hi, int Wi, int P, int ignore_rule, float eps_den, int kind,
+                float beta, hipStream_t stream);
+int pa_loss_bwd(const float* pred, const float* tgts, const float* valid, const unsigned char* mask,
+                int mask_batch_stride, const float* dloss, const float* loss_out, float* dpred, int batch, int Hi, int Wi,
+                int P, int kind, float beta, hipStream_t stream);
+/* patchify (models_painter.py:355-368): f32 NCHW -> [B, L, P*P*3] */
+int pa_patchify(const float* img, float* out, int batch, int Hp, int Wp, int P, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -380,6 +380,12 @@ def tiny_config(seggpt: bool = False) -> OracleConfig:
                         decoder_embed_dim=8, seggpt=seggpt)
 
 
+def small_config(seggpt: bool = False) -> OracleConfig:
+    """Smallest shape the HIP path supports (head_dim 64, decoder_embed_dim 64, 8x4 token grid): the GPU tests'
+    fast whole-model case.  Golden vectors for it come from the unmodified reference (tests/golden/painter_small.npz)."""
+    return OracleConfig(img_size=(128, 64), embed_dim=128, depth=24, num_heads=2, decoder_embed_dim=64, seggpt=seggpt)
+
+
 def vit_large_config(seggpt: bool = False) -> OracleConfig:
     """Painter/models_painter.py:476-487 / models_seggpt.py:483-494."""
     return OracleConfig(seggpt=seggpt)

@@ -1,0 +1,513 @@
+// Fused attention backward (autograd of Painter/models_painter.py:76-86 + util/vitdet_utils.py:96-125;
+// SURVEY.md 8a a17, Appendix B.2).  P is recomputed from the saved row log-sum-exp; nothing L x L is stored.
+//
+//   Delta[q] = sum_d dO[q,d] O[q,d]                                 (pa_attn_bwd_delta)
+//   dS = P o (dP - Delta),  dP = dO V^T
+//   kernel A (lane = query row, loops over key tiles):
+//       dQ = scale dS K + dG Rcat            dG[q][r] = r-space scatter of the k-space bias-gradient tables
+//       tabg[q][kh] += sum_kw dS,  tabg[q][Hp+kw] += sum_kh dS      (LDS: ds_add_f32 / in-order RMW)
+//       exports  aux[bh][qtile][TS+2][32] = transposed bias table (x log2 e), lse*log2 e, Delta
+//                dG[R][H][NRP] (T) for the rel_pos_h / rel_pos_w weight gradient (a TN contraction on the GEMM engine)
+//   kernel B (lane = key, loops over query tiles):
+//       dV = P^T dO,   dK = scale dS^T Q        (bias / lse / Delta come from `aux`, 16-byte reads)
+#include "attn_common.h"
+#include "gemm_engine.h"
+#include "../../include/painter_hip.h"
+
+// ------------------------------------------------------------------------------- Delta pre-pass
+template <typename T> __global__ void attn_delta_kernel(const T* o, size_t ldo, const T* d_o, size_t lddo, float* delta, int R, int L, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= R) return;
+    const int b = row / L, l = row % L;
+    const int D = H * ATT_HD;
+    for (int c = lane * 16; c < D; c += 1024) {
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += to_f(o[(size_t)row * ldo + c + e]) * to_f(d_o[(size_t)row * lddo + c + e]);
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if ((lane & 3) == 0) delta[((size_t)b * H + c / ATT_HD) * L + l] = s;
+    }
+}
+extern "C" int pa_attn_bwd_delta(int dtype, const void* out, int64_t ldo, const void* dout, int64_t lddo, float* delta, int batch, int L,
+                                 int heads, hipStream_t st) {
+    const int R = batch * L;
+    if (dtype == PA_BF16)
+        hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3((R + 3) / 4), dim3(256), 0, st, (const bf16*)out, (size_t)ldo, (const bf16*)dout, (size_t)lddo, delta, R, L, heads);
+    else
+        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, st, (const float*)out, (size_t)ldo, (const float*)dout, (size_t)lddo, delta, R, L, heads);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------- kernel A: dQ + bias-gradient tables
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const T* __restrict__ qkv, size_t ldq, const T* __restrict__ rcat,
+                                                              const T* __restrict__ rcatT, const T* __restrict__ dout, size_t lddo,
+                                                              const float* __restrict__ lse, const float* __restrict__ delta,
+                                                              T* __restrict__ dqkv, T* __restrict__ dG, float* __restrict__ aux, int L,
+                                                              int H, int Hp, int Wp, int NRP, float scale, int tab_stride) {
+    constexpr int NT = NW * 64;
+    constexpr int KVB = KvTile<T>::BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int D = H * ATT_HD, TS = Hp + Wp;
+    const T* base = qkv + (size_t)b * L * ldq + h * ATT_HD;
+    const T* kbase = base + D;
+    const T* vbase = base + 2 * D;
+    const int qt = blockIdx.x * NW + wave;
+    const bool valid = qt * 32 < L;
+    const int q = qt * 32 + (lane & 31);
+    const int qh = q / Wp, qw = q % Wp;
+    // LDS: stage s in {0,1}: K row image, K^T image, V row image; then per-wave [bias table | grad table]
+    unsigned char* wreg = smem + 6 * KVB + (size_t)wave * tab_stride;
+    float* tab = reinterpret_cast<float*>(wreg) + (lane & 31) * TS;
+    float* tabg = reinterpret_cast<float*>(wreg) + 32 * TS + (lane & 31) * TS;
+
+    Frag<T> qf[4], dof[4];
+    float lse2 = 0.f, dlt = 0.f;
+    if (valid) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            load_gfrag<T>(qf[s], base + (size_t)q * ldq, s, g);
+            load_gfrag<T>(dof[s], dout + (size_t)(b * L + q) * lddo + h * ATT_HD, s, g);
+        }
+        lse2 = lse[(size_t)bh * L + q] * LOG2E_F;
+        dlt = delta[(size_t)bh * L + q];
+        build_bias_table<T>(tab, rcat, NRP, qf, qh, qw, Hp, Wp, lane);
+        for (int c = g; c < TS; c += 2) tabg[c] = 0.f;
+        // export the transposed table + per-row scalars for kernel B
+        float* ax = aux + ((size_t)bh * (L / 32) + qt) * (TS + 2) * 32 + (lane & 31);
+        for (int c = g; c < TS; c += 2) ax[(size_t)c * 32] = tab[c];      // own-wave LDS writes above are in order
+        if (g == 0) ax[(size_t)TS * 32] = lse2;
+        else ax[(size_t)(TS + 1) * 32] = dlt;
+    }
+
+    RowStage<T, NT> ks, vs;
+    TrStage<T> kts;
+    const int ntile = L / 32;
+    ks.load(kbase, ldq, tid);
+    kts.load(kbase, ldq, tid);
+    vs.load(vbase, ldq, tid);
+    ks.store(smem, tid);
+    kts.store(smem + KVB, tid);
+    vs.store(smem + 2 * KVB, tid);
+    __syncthreads();
+
+    f32x16 dq[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+    const float sl = scale * LOG2E_F;
+    int kh[4], kw[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int ks0 = 8 * rg + 4 * g;
+        kh[rg] = ks0 / Wp;
+        kw[rg] = ks0 % Wp;
+    }
+    const int dq_ = 32 / Wp, dr_ = 32 % Wp;
+
+    for (int j = 0; j < ntile; ++j) {
+        if (j + 1 < ntile) {
+            const T* kp = kbase + (size_t)(j + 1) * 32 * ldq;
+            ks.load(kp, ldq, tid);
+            kts.load(kp, ldq, tid);
+            vs.load(vbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
+        }
+        const unsigned char* st = smem + (j & 1) * 3 * KVB;
+        if (valid) {
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                Frag<T> kf, vf;
+                load_rowfrag<T>(kf, st, lane & 31, s, g);
+                load_rowfrag<T>(vf, st + 2 * KVB, lane & 31, s, g);
+                mma(sacc, kf, qf[s]);
+                mma(dpacc, vf, dof[s]);
+            }
+            float ds[16];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float bhv = tab[kh[rg]];
+                const float4 bw = *reinterpret_cast<const float4*>(tab + Hp + kw[rg]);
+                const float p0 = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 0], sl, bhv + bw.x) - lse2);
+                const float p1 = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 1], sl, bhv + bw.y) - lse2);
+                const float p2 = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 2], sl, bhv + bw.z) - lse2);
+                const float p3 = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 3], sl, bhv + bw.w) - lse2);
+                ds[rg * 4 + 0] = p0 * (dpacc[rg * 4 + 0] - dlt);
+                ds[rg * 4 + 1] = p1 * (dpacc[rg * 4 + 1] - dlt);
+                ds[rg * 4 + 2] = p2 * (dpacc[rg * 4 + 2] - dlt);
+                ds[rg * 4 + 3] = p3 * (dpacc[rg * 4 + 3] - dlt);
+                atomicAdd(tabg + kh[rg], (ds[rg * 4] + ds[rg * 4 + 1]) + (ds[rg * 4 + 2] + ds[rg * 4 + 3]));
+                if (Wp >= 8) {      // the two half-waves of a query own disjoint kw runs (kw0 and kw0 + 4): in-order RMW
+                    float4* gw = reinterpret_cast<float4*>(tabg + Hp + kw[rg]);
+                    float4 cur = *gw;
+                    cur.x += ds[rg * 4]; cur.y += ds[rg * 4 + 1]; cur.z += ds[rg * 4 + 2]; cur.w += ds[rg * 4 + 3];
+                    *gw = cur;
+                } else {            // Wp == 4: both halves hit kw 0..3 in the same instruction
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd(tabg + Hp + kw[rg] + e, ds[rg * 4 + e]);
+                }
+            }
+            Frag<T> dsf[2];
+            pack_frag<T>(dsf[0], ds);
+            pack_frag<T>(dsf[1], ds + 8);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    Frag<T> ktf;
+                    load_trfrag<T>(ktf, st + KVB, db * 32 + (lane & 31), s, g);
+                    mma(dq[db], ktf, dsf[s]);
+                }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                kh[rg] += dq_;
+                kw[rg] += dr_;
+                if (kw[rg] >= Wp) { kw[rg] -= Wp; kh[rg] += 1; }
+            }
+        }
+        if (j + 1 < ntile) {
+            unsigned char* sn = smem + ((j + 1) & 1) * 3 * KVB;
+            ks.store(sn, tid);
+            kts.store(sn + KVB, tid);
+            vs.store(sn + 2 * KVB, tid);
+        }
+        __syncthreads();
+    }
+
+    // bias part of dQ through r-space: dQ^T[d][q] = scale * acc + sum_r Rcat[r][d] dG[q][r]; also emit dG (T)
+    constexpr int ROWB = ATT_HD * sizeof(T);
+    if (valid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[0][r] *= scale; dq[1][r] *= scale; }
+        T* dgrow = dG + ((size_t)(b * L + q) * H + h) * NRP;
+        for (int s = 0; s < NRP / 16; ++s) {
+            float gv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int r = 16 * s + 8 * g + t;
+                float v = 0.f;
+                if (r < 2 * Hp - 1) {
+                    const int khh = qh + Hp - 1 - r;
+                    if (khh >= 0 && khh < Hp) v = tabg[khh];
+                } else {
+                    const int rr = r - (2 * Hp - 1);
+                    const int kww = qw + Wp - 1 - rr;
+                    if (rr < 2 * Wp - 1 && kww >= 0 && kww < Wp) v = tabg[Hp + kww];
+                }
+                gv[t] = v;
+            }
+            Frag<T> gf;
+            pack_frag<T>(gf, gv);
+            if constexpr (sizeof(T) == 2) {
+                *reinterpret_cast<uint4*>(dgrow + 16 * s + 8 * g) = __builtin_bit_cast(uint4, gf.v);
+            } else {
+                *reinterpret_cast<float4*>(dgrow + 16 * s + 8 * g) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+                *reinterpret_cast<float4*>(dgrow + 16 * s + 8 * g + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
+            }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                Frag<T> rf;
+                const T* rp = rcatT + (size_t)(db * 32 + (lane & 31)) * NRP + 16 * s + 8 * g;
+                if constexpr (sizeof(T) == 2) rf.set(*reinterpret_cast<const uint4*>(rp));
+                else rf.set(*reinterpret_cast<const uint4*>(rp), *reinterpret_cast<const uint4*>(rp + 4));
+                mma(dq[db], rf, gf);
+            }
+        }
+    }
+    __syncthreads();      // every wave is done with its tables -> reuse the region as the dQ staging tile
+    if (valid) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d0 = db * 32 + 8 * rg + 4 * g;
+                T* dst = reinterpret_cast<T*>(wreg + (lane & 31) * ROWB) + d0;
+                *reinterpret_cast<typename TT<T>::Vec4*>(dst) =
+                    cvt4(dq[db][rg * 4], dq[db][rg * 4 + 1], dq[db][rg * 4 + 2], dq[db][rg * 4 + 3], (T*)nullptr);
+            }
+    }
+    __syncthreads();
+    if (valid) {
+        constexpr int CPR = ROWB / 16;
+#pragma unroll
+        for (int i = 0; i < 32 * CPR / 64; ++i) {
+            const int c = lane + 64 * i, row = c / CPR, ch = c % CPR;
+            const uint4 v = *reinterpret_cast<const uint4*>(wreg + row * ROWB + ch * 16);
+            *reinterpret_cast<uint4*>(dqkv + (size_t)(b * L + qt * 32 + row) * ldq + h * ATT_HD + ch * TT<T>::EPC) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- kernel B: dK, dV
+#define AUX_LD 36   // floats per LDS row of the transposed aux tile (32 + 4 pad: conflict-free 16-B reads)
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, size_t ldq, const T* __restrict__ dout,
+                                                               size_t lddo, const float* __restrict__ aux, T* __restrict__ dqkv, int L,
+                                                               int H, int Hp, int Wp, float scale) {
+    constexpr int NT = NW * 64;
+    constexpr int KVB = KvTile<T>::BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int D = H * ATT_HD, TS = Hp + Wp;
+    const int AUXB = (TS + 2) * AUX_LD * 4;
+    const int STG = 4 * KVB + AUXB;            // Q row, Q^T, dO row, dO^T, aux
+    const T* qbase = qkv + (size_t)b * L * ldq + h * ATT_HD;
+    const T* dobase = dout + (size_t)b * L * lddo + h * ATT_HD;
+    const int kt = blockIdx.x * NW + wave;
+    const bool valid = kt * 32 < L;
+    const int key = kt * 32 + (lane & 31);
+    const int khl = key / Wp, kwl = key % Wp;
+
+    Frag<T> kf[4], vf[4];
+    if (valid) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            load_gfrag<T>(kf[s], qbase + D + (size_t)key * ldq, s, g);
+            load_gfrag<T>(vf[s], qbase + 2 * D + (size_t)key * ldq, s, g);
+        }
+    }
+    RowStage<T, NT> qs, dos;
+    TrStage<T> qts, dots;
+    const int NAUX = (TS + 2) * 8;                       // 16-B chunks of the aux tile
+    constexpr int CAUX = 3;                              // up to 3 * NT chunks (TS + 2 <= 3 * NT / 8)
+    uint4 ra[CAUX];
+    const int ntile = L / 32;
+    auto load_all = [&](int j) {
+        qs.load(qbase + (size_t)j * 32 * ldq, ldq, tid);
+        qts.load(qbase + (size_t)j * 32 * ldq, ldq, tid);
+        dos.load(dobase + (size_t)j * 32 * lddo, lddo, tid);
+        dots.load(dobase + (size_t)j * 32 * lddo, lddo, tid);
+        const float* ax = aux + ((size_t)bh * ntile + j) * (TS + 2) * 32;
+#pragma unroll
+        for (int i = 0; i < CAUX; ++i) {
+            const int c = tid + NT * i;
+            if (c < NAUX) ra[i] = *reinterpret_cast<const uint4*>(ax + (size_t)c * 4);
+        }
+    };
+    auto store_all = [&](int stage) {
+        unsigned char* s0 = smem + stage * STG;
+        qs.store(s0, tid);
+        qts.store(s0 + KVB, tid);
+        dos.store(s0 + 2 * KVB, tid);
+        dots.store(s0 + 3 * KVB, tid);
+#pragma unroll
+        for (int i = 0; i < CAUX; ++i) {
+            const int c = tid + NT * i;
+            if (c < NAUX) *reinterpret_cast<uint4*>(s0 + 4 * KVB + (c >> 3) * (AUX_LD * 4) + (c & 7) * 16) = ra[i];
+        }
+    };
+    load_all(0);
+    store_all(0);
+    __syncthreads();
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+    const float sl = scale * LOG2E_F;
+
+    for (int j = 0; j < ntile; ++j) {
+        if (j + 1 < ntile) load_all(j + 1);
+        const unsigned char* st = smem + (j & 1) * STG;
+        if (valid) {
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                Frag<T> qf, dof;
+                load_rowfrag<T>(qf, st, lane & 31, s, g);
+                load_rowfrag<T>(dof, st + 2 * KVB, lane & 31, s, g);
+                mma(sacc, qf, kf[s]);          // S[q][key]: lane = key, regs = q rows
+                mma(dpacc, dof, vf[s]);        // dP[q][key]
+            }
+            const float* ax = reinterpret_cast<const float*>(st + 4 * KVB);
+            float p[16], ds[16];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int q0 = 8 * rg + 4 * g;
+                const float4 bh4 = *reinterpret_cast<const float4*>(ax + khl * AUX_LD + q0);
+                const float4 bw4 = *reinterpret_cast<const float4*>(ax + (Hp + kwl) * AUX_LD + q0);
+                const float4 ls4 = *reinterpret_cast<const float4*>(ax + TS * AUX_LD + q0);
+                const float4 dl4 = *reinterpret_cast<const float4*>(ax + (TS + 1) * AUX_LD + q0);
+                p[rg * 4 + 0] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 0], sl, bh4.x + bw4.x) - ls4.x);
+                p[rg * 4 + 1] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 1], sl, bh4.y + bw4.y) - ls4.y);
+                p[rg * 4 + 2] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 2], sl, bh4.z + bw4.z) - ls4.z);
+                p[rg * 4 + 3] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 3], sl, bh4.w + bw4.w) - ls4.w);
+                ds[rg * 4 + 0] = p[rg * 4 + 0] * (dpacc[rg * 4 + 0] - dl4.x);
+                ds[rg * 4 + 1] = p[rg * 4 + 1] * (dpacc[rg * 4 + 1] - dl4.y);
+                ds[rg * 4 + 2] = p[rg * 4 + 2] * (dpacc[rg * 4 + 2] - dl4.z);
+                ds[rg * 4 + 3] = p[rg * 4 + 3] * (dpacc[rg * 4 + 3] - dl4.w);
+            }
+            Frag<T> pf[2], dsf[2];
+            pack_frag<T>(pf[0], p);
+            pack_frag<T>(pf[1], p + 8);
+            pack_frag<T>(dsf[0], ds);
+            pack_frag<T>(dsf[1], ds + 8);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    Frag<T> qtf, dotf;
+                    load_trfrag<T>(dotf, st + 3 * KVB, db * 32 + (lane & 31), s, g);
+                    load_trfrag<T>(qtf, st + KVB, db * 32 + (lane & 31), s, g);
+                    mma(dv[db], dotf, pf[s]);      // dV^T[d][key] += dO^T[d][q] P[q][key]
+                    mma(dk[db], qtf, dsf[s]);      // dK^T[d][key] += Q^T[d][q] dS[q][key]
+                }
+        }
+        if (j + 1 < ntile) store_all((j + 1) & 1);
+        __syncthreads();
+    }
+
+    // store dK (x scale) and dV rows through a per-wave LDS staging tile
+    constexpr int ROWB = ATT_HD * sizeof(T);
+    unsigned char* stg = smem + (size_t)wave * 2 * 32 * ROWB;
+    if (valid) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int d0 = db * 32 + 8 * rg + 4 * g;
+                T* dstk = reinterpret_cast<T*>(stg + (lane & 31) * ROWB) + d0;
+                T* dstv = reinterpret_cast<T*>(stg + 32 * ROWB + (lane & 31) * ROWB) + d0;
+                *reinterpret_cast<typename TT<T>::Vec4*>(dstk) = cvt4(dk[db][rg * 4] * scale, dk[db][rg * 4 + 1] * scale,
+                                                                    dk[db][rg * 4 + 2] * scale, dk[db][rg * 4 + 3] * scale, (T*)nullptr);
+                *reinterpret_cast<typename TT<T>::Vec4*>(dstv) =
+                    cvt4(dv[db][rg * 4], dv[db][rg * 4 + 1], dv[db][rg * 4 + 2], dv[db][rg * 4 + 3], (T*)nullptr);
+            }
+    }
+    __syncthreads();
+    if (valid) {
+        constexpr int CPR = ROWB / 16;
+#pragma unroll
+        for (int i = 0; i < 32 * CPR / 64; ++i) {
+            const int c = lane + 64 * i, row = c / CPR, ch = c % CPR;
+            T* orow = dqkv + (size_t)(b * L + kt * 32 + row) * ldq + h * ATT_HD + ch * TT<T>::EPC;
+            *reinterpret_cast<uint4*>(orow + D) = *reinterpret_cast<const uint4*>(stg + row * ROWB + ch * 16);
+            *reinterpret_cast<uint4*>(orow + 2 * D) = *reinterpret_cast<const uint4*>(stg + 32 * ROWB + row * ROWB + ch * 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------- host side
+// RcatT[d][r] (T) -- the transposed operand of the dQ bias contraction
+template <typename T> __global__ void relpos_pack_t_kernel(const float* rh, int nh, const float* rw, int nw, T* out, int NRP) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NRP * ATT_HD) return;
+    const int d = i / NRP, r = i % NRP;
+    float v = 0.f;
+    if (r < nh) v = rh[r * ATT_HD + d];
+    else if (r - nh < nw) v = rw[(r - nh) * ATT_HD + d];
+    out[i] = from_f<T>(v);
+}
+extern "C" int pa_relpos_rows_padded(int Hp, int Wp);
+extern "C" int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcatT, int Hp, int Wp, hipStream_t st) {
+    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    const int n = NRP * ATT_HD;
+    if (dtype == PA_BF16)
+        hipLaunchKernelGGL(relpos_pack_t_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (bf16*)rcatT, NRP);
+    else
+        hipLaunchKernelGGL(relpos_pack_t_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (float*)rcatT, NRP);
+    LAUNCH_CHECK();
+}
+
+extern "C" int64_t pa_attn_bwd_aux_bytes(int batch, int L, int heads, int Hp, int Wp) {
+    return (int64_t)batch * heads * (L / 32) * (Hp + Wp + 2) * 32 * sizeof(float);
+}
+
+template <typename T>
+static int attn_bwd_t(const T* qkv, int64_t ldq, const T* rcat, const T* rcatT, const T* dout, int64_t lddo, const float* lse,
+                      const float* delta, T* dqkv, T* dG, float* aux, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st) {
+    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    const int TS = Hp + Wp;
+    constexpr int KVB = KvTile<T>::BYTES;
+    const int qtiles = L / 32;
+    {   // kernel A
+        constexpr int NW = 4;
+        int ts = 2 * 32 * TS * 4;
+        const int stg = 32 * ATT_HD * (int)sizeof(T);
+        if (ts < stg) ts = stg;
+        ts = (ts + 15) / 16 * 16;
+        const size_t smem = 6 * KVB + (size_t)NW * ts;
+        if (smem > 160 * 1024) return (int)hipErrorInvalidValue;
+        auto kern = attn_bwd_dq_kernel<T, NW>;
+        static bool done = false;
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((qtiles + NW - 1) / NW, Bn * H), dim3(NW * 64), smem, st, qkv, (size_t)ldq, rcat, rcatT, dout,
+                           (size_t)lddo, lse, delta, dqkv, dG, aux, L, H, Hp, Wp, NRP, scale, ts);
+        int e = (int)hipGetLastError();
+        if (e) return e;
+    }
+    {   // kernel B
+        constexpr int NW = 4;
+        const int AUXB = (TS + 2) * AUX_LD * 4;
+        size_t smem = 2 * (size_t)(4 * KVB + AUXB);
+        const size_t stg = (size_t)NW * 2 * 32 * ATT_HD * sizeof(T);
+        if (smem < stg) smem = stg;
+        if (smem > 160 * 1024 || (TS + 2) * 8 > 3 * NW * 64) return (int)hipErrorInvalidValue;
+        auto kern = attn_bwd_dkv_kernel<T, NW>;
+        static bool done = false;
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return (int)e;
+            done = true;
+        }
+        hipLaunchKernelGGL(kern, dim3((qtiles + NW - 1) / NW, Bn * H), dim3(NW * 64), smem, st, qkv, (size_t)ldq, dout, (size_t)lddo,
+                           aux, dqkv, L, H, Hp, Wp, scale);
+        return (int)hipGetLastError();
+    }
+}
+
+// dqkv: T [batch*L, 3*heads*64] (same layout as qkv); dG: T [batch*L, heads*NRP]; aux: pa_attn_bwd_aux_bytes scratch
+extern "C" int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, const void* rcatT, const void* dout, int64_t lddo,
+                           const float* lse, const float* delta, void* dqkv, void* dG, void* aux, int batch, int L, int heads, int Hp,
+                           int Wp, float scale, hipStream_t st) {
+    if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4) return (int)hipErrorInvalidValue;
+    if (dtype == PA_BF16)
+        return attn_bwd_t<bf16>((const bf16*)qkv, ldq, (const bf16*)rcat, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta,
+                                (bf16*)dqkv, (bf16*)dG, (float*)aux, batch, L, heads, Hp, Wp, scale, st);
+    return attn_bwd_t<float>((const float*)qkv, ldq, (const float*)rcat, (const float*)rcatT, (const float*)dout, lddo, lse, delta,
+                             (float*)dqkv, (float*)dG, (float*)aux, batch, L, heads, Hp, Wp, scale, st);
+}
+
+// d[rel_pos_h ; rel_pos_w ; pad][NRP, 64] (fp32) = sum over heads, samples, queries of dG[., r] * q[., d]
+extern "C" int64_t pa_attn_bwd_relpos_workspace_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp) {
+    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    return (int64_t)heads * 32 * NRP * ATT_HD * sizeof(float);
+}
+template <typename T>
+static int relpos_grad_t(const T* dG, const T* qkv, int64_t ldq, float* drcat, float* ws, int Bn, int L, int H, int NRP, hipStream_t st) {
+    const int R = Bn * L;
+    OpT<T> A{dG, (size_t)H * NRP, NRP, (size_t)NRP};
+    OpT<T> B{qkv, (size_t)ldq, ATT_HD, (size_t)ATT_HD};
+    const int nku = (R + TT<T>::BK - 1) / TT<T>::BK;
+    int splits = 32;
+    if (splits > nku) splits = nku;
+    struct Epi {
+        float* out; size_t slab; int M, N;
+        DEVI void operator()(const f32x16 (&acc)[2][2], int ib, int jb, int lane, int z) const {
+            float* o = out + (size_t)z * slab;
+            foreach_acc(acc, ib, jb, lane, [&](int i, int j, float v) {
+                if (i < M && j < N) o[(size_t)i * N + j] = v;
+            });
+        }
+    };
+    int e = launch_gemm<T, 2, 2>(A, B, Epi{ws, (size_t)NRP * ATT_HD, NRP, ATT_HD}, NRP, ATT_HD, R, splits, H, st);
+    if (e) return e;
+    return pa_slab_reduce(ws, drcat, (int64_t)NRP * ATT_HD, splits * H, (int64_t)NRP * ATT_HD, 0, st);
+}
+extern "C" int pa_attn_bwd_relpos(int dtype, const void* dG, const void* qkv, int64_t ldq, float* drcat, void* workspace, int batch, int L,
+                                  int heads, int Hp, int Wp, hipStream_t st) {
+    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    if (dtype == PA_BF16) return relpos_grad_t<bf16>((const bf16*)dG, (const bf16*)qkv, ldq, drcat, (float*)workspace, batch, L, heads, NRP, st);
+    return relpos_grad_t<float>((const float*)dG, (const float*)qkv, ldq, drcat, (float*)workspace, batch, L, heads, NRP, st);
+}

@@ -1,0 +1,423 @@
+// HBM-bound pieces of the path: abs-pos resize operator, token-assembly backward, stream merge, SegGPT feature
+// ensemble, masked smooth-L1 loss (+ ignore rule) forward/backward, patchify, decoder-tail point-wise backward,
+// parameter casts.  Reference lines are cited per kernel (paths relative to the reference root).
+#include "common.h"
+#include "../../include/painter_hip.h"
+
+extern "C" int pa_slab_reduce(const float* in, float* out, int64_t n, int nz, int64_t stride, int accumulate, hipStream_t st);
+
+// ------------------------------------------------------------------------------- casts (autocast's weight casts, once per step)
+__global__ void cast_bf16_kernel(const float* __restrict__ in, bf16* __restrict__ out, size_t n) {
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 4 <= n) {
+        const float4 v = *reinterpret_cast<const float4*>(in + i);
+        *reinterpret_cast<uint2*>(out + i) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    } else {
+        for (; i < n; ++i) out[i] = (bf16)in[i];
+    }
+}
+extern "C" int pa_cast_bf16(const float* in, void* out, int64_t n, hipStream_t st) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, in, (bf16*)out, (size_t)n);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------- abs pos: pos = M . pos_embed[0, skip:]
+// get_abs_pos (util/vitdet_utils.py:128-157) as the constant bicubic operator M [L, S].
+__global__ void pos_fwd_kernel(const float* __restrict__ M, const float* __restrict__ pe, float* __restrict__ pos, int L, int S, int D) {
+    const int l = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= D) return;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) {
+        const float m = M[(size_t)l * S + s];
+        if (m != 0.f) acc = fmaf(m, pe[(size_t)s * D + n], acc);
+    }
+    pos[(size_t)l * D + n] = acc;
+}
+__global__ void pos_bwd_kernel(const float* __restrict__ M, const float* __restrict__ g0, const float* __restrict__ g1,
+                               float* __restrict__ dpe, int L, int S, int D) {
+    const int s = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= D) return;
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const float m = M[(size_t)l * S + s];
+        if (m != 0.f) acc = fmaf(m, g0[(size_t)l * D + n] + g1[(size_t)l * D + n], acc);
+    }
+    dpe[(size_t)s * D + n] = acc;
+}
+// pe / dpe point at the first non-cls row of pos_embed ([S, D])
+extern "C" int pa_pos_fwd(const float* M, const float* pe, float* pos, int L, int S, int D, hipStream_t st) {
+    hipLaunchKernelGGL(pos_fwd_kernel, dim3((D + 255) / 256, L), dim3(256), 0, st, M, pe, pos, L, S, D);
+    LAUNCH_CHECK();
+}
+extern "C" int pa_pos_bwd(const float* M, const float* gx, const float* gy, float* dpe, int L, int S, int D, hipStream_t st) {
+    hipLaunchKernelGGL(pos_bwd_kernel, dim3((D + 255) / 256, S), dim3(256), 0, st, M, gx, gy, dpe, L, S, D);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------- token assembly backward (models_painter.py:392-409)
+// dPE[x rows] = dx; dPE[y rows] = dy * (1 - w); sums[0][l] = sum_b dx, sums[1][l] = sum_b dy, sums[2][l] = sum_b w dy
+template <typename T>
+__global__ void tokens_bwd_kernel(const float* __restrict__ dx0, const unsigned char* __restrict__ mask, int mbs, T* __restrict__ dpe,
+                                  float* __restrict__ sums, int Bn, int L, int D) {
+    const int l = blockIdx.y, n = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (n >= D) return;
+    float4 sx = make_float4(0, 0, 0, 0), sy = sx, sm = sx;
+    for (int b = 0; b < Bn; ++b) {
+        const size_t rx = ((size_t)b * L + l) * D + n, ry = ((size_t)(Bn + b) * L + l) * D + n;
+        const float4 gx = *reinterpret_cast<const float4*>(dx0 + rx), gy = *reinterpret_cast<const float4*>(dx0 + ry);
+        const float w = mask[(size_t)b * mbs + l] ? 1.f : 0.f;
+        sx.x += gx.x; sx.y += gx.y; sx.z += gx.z; sx.w += gx.w;
+        sy.x += gy.x; sy.y += gy.y; sy.z += gy.z; sy.w += gy.w;
+        sm.x += w * gy.x; sm.y += w * gy.y; sm.z += w * gy.z; sm.w += w * gy.w;
+        const float k = 1.f - w;
+        *reinterpret_cast<typename TT<T>::Vec4*>(dpe + rx) = cvt4(gx.x, gx.y, gx.z, gx.w, (T*)nullptr);
+        *reinterpret_cast<typename TT<T>::Vec4*>(dpe + ry) = cvt4(gy.x * k, gy.y * k, gy.z * k, gy.w * k, (T*)nullptr);
+    }
+    const size_t o = (size_t)l * D + n, LD = (size_t)L * D;
+    *reinterpret_cast<float4*>(sums + o) = sx;
+    *reinterpret_cast<float4*>(sums + LD + o) = sy;
+    *reinterpret_cast<float4*>(sums + 2 * LD + o) = sm;
+}
+extern "C" int pa_tokens_bwd(int dtype, const float* dx0, const unsigned char* mask, int mask_batch_stride, void* dpe, float* sums,
+                             int batch, int L, int D, hipStream_t st) {
+    if (D % 4) return (int)hipErrorInvalidValue;
+    dim3 grid((D / 4 + 63) / 64, L);
+    if (dtype == PA_BF16) hipLaunchKernelGGL(tokens_bwd_kernel<bf16>, grid, dim3(64), 0, st, dx0, mask, mask_batch_stride, (bf16*)dpe, sums, batch, L, D);
+    else hipLaunchKernelGGL(tokens_bwd_kernel<float>, grid, dim3(64), 0, st, dx0, mask, mask_batch_stride, (float*)dpe, sums, batch, L, D);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------- stream merge (models_painter.py:414-415)
+__global__ void merge_fwd_kernel(const float* __restrict__ x, float* __restrict__ out, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 a = *reinterpret_cast<const float4*>(x + i), b = *reinterpret_cast<const float4*>(x + n + i);
+    *reinterpret_cast<float4*>(out + i) = make_float4((a.x + b.x) * 0.5f, (a.y + b.y) * 0.5f, (a.z + b.z) * 0.5f, (a.w + b.w) * 0.5f);
+}
+extern "C" int pa_merge_fwd(const float* x, float* out, int64_t n_out, hipStream_t st) {
+    if (n_out % 4) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(merge_fwd_kernel, dim3((unsigned)((n_out / 4 + 255) / 256)), dim3(256), 0, st, x, out, (size_t)n_out);
+    LAUNCH_CHECK();
+}
+// dx[both halves] = 0.5 * dmerged; dxT = rowscale[row / rps] * dx (T copy for the next GEMM operand)
+template <typename T>
+__global__ void merge_bwd_kernel(const float* __restrict__ dm, float* __restrict__ dx, T* __restrict__ dxT, const float* __restrict__ rowscale,
+                                 int rps, size_t rows_half, int D) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t n = rows_half * D;
+    if (i >= n) return;
+    const float4 g = *reinterpret_cast<const float4*>(dm + i);
+    const float4 h = make_float4(g.x * 0.5f, g.y * 0.5f, g.z * 0.5f, g.w * 0.5f);
+    *reinterpret_cast<float4*>(dx + i) = h;
+    *reinterpret_cast<float4*>(dx + n + i) = h;
+    const size_t row = i / D;
+    const float s0 = rowscale ? rowscale[row / rps] : 1.f, s1 = rowscale ? rowscale[(row + rows_half) / rps] : 1.f;
+    *reinterpret_cast<typename TT<T>::Vec4*>(dxT + i) = cvt4(h.x * s0, h.y * s0, h.z * s0, h.w * s0, (T*)nullptr);
+    *reinterpret_cast<typename TT<T>::Vec4*>(dxT + n + i) = cvt4(h.x * s1, h.y * s1, h.z * s1, h.w * s1, (T*)nullptr);
+}
+extern "C" int pa_merge_bwd(int dtype, const float* dmerged, float* dx, void* dxT, const float* rowscale, int rows_per_sample,
+                            int64_t rows_half, int D, hipStream_t st) {
+    if (D % 4) return (int)hipErrorInvalidValue;
+    const size_t n = (size_t)rows_half * D;
+    dim3 grid((unsigned)((n / 4 + 255) / 256));
+    if (dtype == PA_BF16) hipLaunchKernelGGL(merge_bwd_kernel<bf16>, grid, dim3(256), 0, st, dmerged, dx, (bf16*)dxT, rowscale, rows_per_sample, (size_t)rows_half, D);
+    else hipLaunchKernelGGL(merge_bwd_kernel<float>, grid, dim3(256), 0, st, dmerged, dx, (float*)dxT, rowscale, rows_per_sample, (size_t)rows_half, D);
+    LAUNCH_CHECK();
+}
+// scaled T copy of an fp32 matrix: out = rowscale[row / rps] * in
+template <typename T>
+__global__ void scale_cast_kernel(const float* __restrict__ in, T* __restrict__ out, const float* __restrict__ rowscale, int rps, size_t n, int D) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    const float4 g = *reinterpret_cast<const float4*>(in + i);
+    const float s = rowscale ? rowscale[(i / D) / rps] : 1.f;
+    *reinterpret_cast<typename TT<T>::Vec4*>(out + i) = cvt4(g.x * s, g.y * s, g.z * s, g.w * s, (T*)nullptr);
+}
+extern "C" int pa_scale_cast(int dtype, const float* in, void* out, const float* rowscale, int rows_per_sample, int64_t rows, int D,
+                             hipStream_t st) {
+    if (D % 4) return (int)hipErrorInvalidValue;
+    const size_t n = (size_t)rows * D;
+    dim3 grid((unsigned)((n / 4 + 255) / 256));
+    if (dtype == PA_BF16) hipLaunchKernelGGL(scale_cast_kernel<bf16>, grid, dim3(256), 0, st, in, (bf16*)out, rowscale, rows_per_sample, n, D);
+    else hipLaunchKernelGGL(scale_cast_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, rowscale, rows_per_sample, n, D);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------- SegGPT feature ensemble (models_seggpt.py:220-232)
+// x1 = x0 + ens(a): tokens of the query half (l >= L/2) use the mean of `a` over the samples of their group.
+__global__ void ensemble_resid_kernel(const float* __restrict__ x0, const float* __restrict__ a, float* __restrict__ x1, int Bn, int G,
+                                      int L, int D) {
+    const int l = blockIdx.y, n = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (n >= D) return;
+    const bool ens = l >= L / 2;
+    for (int g0 = 0; g0 < Bn; g0 += G) {
+        float4 m = make_float4(0, 0, 0, 0);
+        if (ens) {
+            for (int b = g0; b < g0 + G; ++b) {
+                const float4 v = *reinterpret_cast<const float4*>(a + ((size_t)b * L + l) * D + n);
+                m.x += v.x; m.y += v.y; m.z += v.z; m.w += v.w;
+            }
+            const float inv = 1.f / (float)G;
+            m.x *= inv; m.y *= inv; m.z *= inv; m.w *= inv;
+        }
+        for (int b = g0; b < g0 + G; ++b) {
+            const size_t o = ((size_t)b * L + l) * D + n;
+            const float4 r = *reinterpret_cast<const float4*>(x0 + o);
+            const float4 v = ens ? m : *reinterpret_cast<const float4*>(a + o);
+            *reinterpret_cast<float4*>(x1 + o) = make_float4(r.x + v.x, r.y + v.y, r.z + v.z, r.w + v.w);
+        }
+    }
+}
+extern "C" int pa_ensemble_resid(const float* x0, const float* a, float* x1, int batch, int group, int L, int D, hipStream_t st) {
+    if (D % 4 || group <= 0 || batch % group) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(ensemble_resid_kernel, dim3((D / 4 + 63) / 64, L), dim3(64), 0, st, x0, a, x1, batch, group, L, D);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------- masked loss (models_painter.py:433-462)
+__constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
+__constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
+#define LOSS_BLK 256
+#define LOSS_CHUNK 4096      // elements per block
+
+DEVI float block_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += sh[i];
+    __syncthreads();
+    return r;      // valid on thread 0
+}
+DEVI int pix_mask(const unsigned char* mask, int mbs, int b, int rem, int Wi, int P, int Wp) {
+    const int y = rem / Wi, x = rem % Wi;
+    return mask[(size_t)b * mbs + (y / P) * Wp + x / P] ? 1 : 0;
+}
+// stage 1 of the ignore rule (:444-448): partial sums of the de-normalised unmasked target
+__global__ void loss_ignore_part_kernel(const float* __restrict__ tgts, const unsigned char* __restrict__ mask, int mbs, float* __restrict__ part,
+                                        int HW, int Wi, int P, int Wp) {
+    __shared__ float sh[LOSS_BLK / 64];
+    const int b = blockIdx.y, n = 3 * HW;
+    float s = 0.f;
+    const int e0 = blockIdx.x * LOSS_CHUNK;
+    for (int e = e0 + threadIdx.x; e < min(n, e0 + LOSS_CHUNK); e += LOSS_BLK) {
+        const int c = e / HW, rem = e % HW;
+        const int m = pix_mask(mask, mbs, b, rem, Wi, P, Wp);
+        s += (tgts[(size_t)b * n + e] * c_std[c] + c_mean[c]) * (1.f - (float)m);
+    }
+    const float r = block_sum(s, sh);
+    if (threadIdx.x == 0) part[(size_t)b * gridDim.x + blockIdx.x] = r;
+}
+__global__ void loss_ignore_flag_kernel(const float* __restrict__ part, int nblk, float* __restrict__ flag, float thresh) {
+    __shared__ float sh[LOSS_BLK / 64];
+    const int b = blockIdx.x;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += LOSS_BLK) s += part[(size_t)b * nblk + i];
+    const float r = block_sum(s, sh);
+    if (threadIdx.x == 0) flag[b] = (r < thresh) ? 1.f : 0.f;
+}
+DEVI float loss_elem(float d, int kind, float beta) {
+    const float a = fabsf(d);
+    if (kind == 0) return a < beta ? 0.5f * d * d / beta : a - 0.5f * beta;     // smooth_l1(beta)
+    if (kind == 1) return a;
+    if (kind == 2) return d * d;
+    return (a + d * d) * 0.5f;
+}
+DEVI float loss_grad_elem(float d, int kind, float beta) {
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    if (kind == 0) return fabsf(d) < beta ? d / beta : sg;
+    if (kind == 1) return sg;
+    if (kind == 2) return 2.f * d;
+    return (sg + 2.f * d) * 0.5f;
+}
+__global__ void loss_part_kernel(const float* __restrict__ pred, const float* __restrict__ tgts, float* valid, const unsigned char* __restrict__ mask,
+                                 int mbs, const float* __restrict__ flag, float* __restrict__ part, int HW, int Wi, int P, int Wp, int kind,
+                                 float beta) {
+    __shared__ float sh[LOSS_BLK / 64];
+    const int b = blockIdx.y, n = 3 * HW;
+    const bool ign = flag && flag[b] != 0.f;
+    float num = 0.f, den = 0.f;
+    const int e0 = blockIdx.x * LOSS_CHUNK;
+    for (int e = e0 + threadIdx.x; e < min(n, e0 + LOSS_CHUNK); e += LOSS_BLK) {
+        const size_t idx = (size_t)b * n + e;
+        float v = valid[idx];
+        if (ign) { v = 0.f; valid[idx] = 0.f; }           // in-place, like the reference (:448)
+        const float mv = (float)pix_mask(mask, mbs, b, e % HW, Wi, P, Wp) * v;
+        num += loss_elem(pred[idx] - tgts[idx], kind, beta) * mv;
+        den += mv;
+    }
+    const float rn = block_sum(num, sh);
+    const float rd = block_sum(den, sh);
+    if (threadIdx.x == 0) {
+        const size_t o = ((size_t)b * gridDim.x + blockIdx.x) * 2;
+        part[o] = rn;
+        part[o + 1] = rd;
+    }
+}
+__global__ void loss_final_kernel(const float* __restrict__ part, int nparts, float eps_den, float* __restrict__ out) {
+    __shared__ float sh[LOSS_BLK / 64];
+    float num = 0.f, den = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += LOSS_BLK) { num += part[2 * (size_t)i]; den += part[2 * (size_t)i + 1]; }
+    const float rn = block_sum(num, sh);
+    const float rd = block_sum(den, sh);
+    if (threadIdx.x == 0) {
+        out[0] = rn / (rd + eps_den);      // loss
+        out[1] = rd + eps_den;             // denominator (for backward)
+    }
+}
+extern "C" int64_t pa_loss_workspace_bytes(int batch, int Hi, int Wi) {
+    const int nblk = (3 * Hi * Wi + LOSS_CHUNK - 1) / LOSS_CHUNK;
+    return (int64_t)batch * nblk * 3 * sizeof(float) + (int64_t)batch * sizeof(float) + 64;
+}
+// out: f32[2] = {loss, denominator}.  ignore_rule=1 (Painter): samples with unmasked target sum < 300 get valid := 0 IN PLACE.
+extern "C" int pa_loss_fwd(const float* pred, const float* tgts, float* valid, const unsigned char* mask, int mask_batch_stride,
+                           float* out, void* workspace, int batch, int Hi, int Wi, int P, int ignore_rule, float eps_den, int kind,
+                           float beta, hipStream_t st) {
+    const int HW = Hi * Wi, Wp = Wi / P;
+    const int nblk = (3 * HW + LOSS_CHUNK - 1) / LOSS_CHUNK;
+    float* part = reinterpret_cast<float*>(workspace);                 // [batch][nblk][2]
+    float* ipart = part + (size_t)batch * nblk * 2;                    // [batch][nblk]
+    float* flag = ipart + (size_t)batch * nblk;                        // [batch]
+    if (ignore_rule) {
+        hipLaunchKernelGGL(loss_ignore_part_kernel, dim3(nblk, batch), dim3(LOSS_BLK), 0, st, tgts, mask, mask_batch_stride, ipart, HW, Wi, P, Wp);
+        hipLaunchKernelGGL(loss_ignore_flag_kernel, dim3(batch), dim3(LOSS_BLK), 0, st, ipart, nblk, flag, 300.f);
+    }
+    hipLaunchKernelGGL(loss_part_kernel, dim3(nblk, batch), dim3(LOSS_BLK), 0, st, pred, tgts, valid, mask, mask_batch_stride,
+                       ignore_rule ? flag : (const float*)nullptr, part, HW, Wi, P, Wp, kind, beta);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(LOSS_BLK), 0, st, part, batch * nblk, eps_den, out);
+    LAUNCH_CHECK();
+}
+__global__ void loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgts, const float* __restrict__ valid,
+                                const unsigned char* __restrict__ mask, int mbs, const float* __restrict__ dloss, const float* __restrict__ lossden,
+                                float* __restrict__ dpred, int HW, int Wi, int P, int Wp, int kind, float beta) {
+    const int b = blockIdx.y, n = 3 * HW;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n) return;
+    const size_t idx = (size_t)b * n + e;
+    const float mv = (float)pix_mask(mask, mbs, b, e % HW, Wi, P, Wp) * valid[idx];
+    dpred[idx] = dloss[0] / lossden[1] * mv * loss_grad_elem(pred[idx] - tgts[idx], kind, beta);
+}
+extern "C" int pa_loss_bwd(const float* pred, const float* tgts, const float* valid, const unsigned char* mask, int mask_batch_stride,
+                           const float* dloss, const float* loss_out, float* dpred, int batch, int Hi, int Wi, int P, int kind,
+                           float beta, hipStream_t st) {
+    const int HW = Hi * Wi;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3((3 * HW + 255) / 256, batch), dim3(256), 0, st, pred, tgts, valid, mask, mask_batch_stride,
+                       dloss, loss_out, dpred, HW, Wi, P, Wi / P, kind, beta);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------- patchify (models_painter.py:355-368), pure index math
+__global__ void patchify_kernel(const float* __restrict__ img, float* __restrict__ out, int Hp, int Wp, int P, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int PP3 = P * P * 3, L = Hp * Wp;
+    const int k = (int)(i % PP3);
+    const size_t t = i / PP3;
+    const int l = (int)(t % L), b = (int)(t / L);
+    const int c = k % 3, q = (k / 3) % P, p = k / (3 * P), h = l / Wp, w = l % Wp;
+    out[i] = img[(((size_t)b * 3 + c) * Hp * P + h * P + p) * (size_t)(Wp * P) + w * P + q];
+}
+extern "C" int pa_patchify(const float* img, float* out, int batch, int Hp, int Wp, int P, hipStream_t st) {
+    const size_t n = (size_t)batch * Hp * Wp * P * P * 3;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, img, out, Hp, Wp, P, n);
+    LAUNCH_CHECK();
+}
+
+// ------------------------------------------------------------------------------- decoder tail point-wise backward
+// Through Conv1x1(64->3), GELU, LayerNorm2D(64) (models_painter.py:328-333, util/vitdet_utils.py:204-209): per pixel
+// 16 lanes x 4 channels; parameter gradients accumulate in registers and leave as one partial row per workgroup:
+// part[blk][0:64]=dgamma [64:128]=dbeta [128:320]=dW1[3][64] [320:323]=db1.
+#define TAILP 324
+template <typename T>
+__global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ dpred, const T* __restrict__ y3, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ w1, T* __restrict__ dy3,
+                                                       float* __restrict__ part, int HW, int npix, float eps) {
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;     // 16 pixel slots per workgroup
+    const int c0 = sub * 4;
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c0), be = *reinterpret_cast<const float4*>(beta + c0);
+    const float4 wa = *reinterpret_cast<const float4*>(w1 + c0), wb = *reinterpret_cast<const float4*>(w1 + 64 + c0),
+                 wc = *reinterpret_cast<const float4*>(w1 + 128 + c0);
+    float ag[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0}, aw[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, ab1[3] = {0, 0, 0};
+    const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
+    const float w4[3][4] = {{wa.x, wa.y, wa.z, wa.w}, {wb.x, wb.y, wb.z, wb.w}, {wc.x, wc.y, wc.z, wc.w}};
+    for (int pix = blockIdx.x * 16 + grp; pix < npix; pix += gridDim.x * 16) {
+        const typename TT<T>::Vec4 raw = *reinterpret_cast<const typename TT<T>::Vec4*>(y3 + (size_t)pix * 64 + c0);
+        float y[4];
+        if constexpr (sizeof(T) == 2) { y[0] = bf16_lo(raw.x); y[1] = bf16_hi(raw.x); y[2] = bf16_lo(raw.y); y[3] = bf16_hi(raw.y); }
+        else { y[0] = __builtin_bit_cast(float, raw.x); y[1] = __builtin_bit_cast(float, raw.y); y[2] = __builtin_bit_cast(float, raw.z); y[3] = __builtin_bit_cast(float, raw.w); }
+        float s = (y[0] + y[1]) + (y[2] + y[3]);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+        const float mu = s * (1.f / 64);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q += (y[e] - mu) * (y[e] - mu);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
+        const float rs = 1.f / sqrtf(q * (1.f / 64) + eps);
+        const int b = pix / HW, rem = pix % HW;
+        const float* dp = dpred + (size_t)b * 3 * HW + rem;
+        const float d0 = dp[0], d1 = dp[(size_t)HW], d2 = dp[(size_t)2 * HW];
+        float dxh[4], xh[4], m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xh[e] = (y[e] - mu) * rs;
+            const float z = xh[e] * g4[e] + b4[e];
+            const float a = gelu_f(z);
+            const float da = d0 * w4[0][e] + d1 * w4[1][e] + d2 * w4[2][e];
+            const float dz = da * gelu_grad_f(z);
+            ag[e] += dz * xh[e];
+            ab[e] += dz;
+            aw[0][e] += d0 * a; aw[1][e] += d1 * a; aw[2][e] += d2 * a;
+            dxh[e] = dz * g4[e];
+            m1 += dxh[e];
+            m2 += dxh[e] * xh[e];
+        }
+        if (sub == 0) { ab1[0] += d0; ab1[1] += d1; ab1[2] += d2; }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+        m1 *= (1.f / 64); m2 *= (1.f / 64);
+        float r[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] = rs * (dxh[e] - m1 - xh[e] * m2);
+        *reinterpret_cast<typename TT<T>::Vec4*>(dy3 + (size_t)pix * 64 + c0) = cvt4(r[0], r[1], r[2], r[3], (T*)nullptr);
+    }
+    __shared__ float red[16][TAILP];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[grp][c0 + e] = ag[e];
+        red[grp][64 + c0 + e] = ab[e];
+        red[grp][128 + c0 + e] = aw[0][e];
+        red[grp][192 + c0 + e] = aw[1][e];
+        red[grp][256 + c0 + e] = aw[2][e];
+    }
+    if (sub == 0) { red[grp][320] = ab1[0]; red[grp][321] = ab1[1]; red[grp][322] = ab1[2]; red[grp][323] = 0.f; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TAILP; i += 256) {
+        float s = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < 16; ++gq) s += red[gq][i];
+        part[(size_t)blockIdx.x * TAILP + i] = s;
+    }
+}
+static int tail_bwd_blocks(int npix) {
+    int b = (npix + 15) / 16;
+    return b > 2048 ? 2048 : b;
+}
+extern "C" int64_t pa_decoder_tail_bwd_workspace_bytes(int batch, int Hi, int Wi) { return (int64_t)tail_bwd_blocks(batch * Hi * Wi) * TAILP * sizeof(float); }
+// grads: f32 [324] = dgamma[64] | dbeta[64] | dW1[3*64] | db1[3] | pad
+extern "C" int pa_decoder_tail_bwd_pointwise(int dtype, const float* dpred, const void* y3, const float* ln_gamma, const float* ln_beta,
+                                             const float* w1, void* dy3, float* grads, void* workspace, int batch, int Hi, int Wi, float eps,
+                                             hipStream_t st) {
+    const int npix = batch * Hi * Wi, nb = tail_bwd_blocks(npix);
+    float* part = reinterpret_cast<float*>(workspace);
+    if (dtype == PA_BF16)
+        hipLaunchKernelGGL(tail_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, dpred, (const bf16*)y3, ln_gamma, ln_beta, w1, (bf16*)dy3, part, Hi * Wi, npix, eps);
+    else
+        hipLaunchKernelGGL(tail_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, dpred, (const float*)y3, ln_gamma, ln_beta, w1, (float*)dy3, part, Hi * Wi, npix, eps);
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    return pa_slab_reduce(part, grads, TAILP, nb, TAILP, 0, st);
+}

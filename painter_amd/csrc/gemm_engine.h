@@ -10,20 +10,24 @@
 // swizzled LDS, next tile's loads in flight under the current tile's MFMAs), one barrier per tile.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------- operand classes
 template <typename T> struct OpN {   // rows x K, K contiguous ("row-major, K innermost")
     static constexpr bool TRANS = false;
     const T* p; size_t ld; int rows; size_t bstride;
+    typedef const T* Ctx;          // per-row context, computed once before the K loop
     DEVI void batch(int b) { p += (size_t)b * bstride; }
-    DEVI uint4 chunk(int row, int k, int kend) const {
-        if (row < rows && k < kend) return *reinterpret_cast<const uint4*>(p + (size_t)row * ld + k);
+    DEVI Ctx ctx(int row) const { return row < rows ? p + (size_t)row * ld : nullptr; }
+    DEVI uint4 chunk(Ctx c, int k, int kend) const {
+        if (c != nullptr && k < kend) return *reinterpret_cast<const uint4*>(c + k);
         return zero4();
     }
 };
 template <typename T> struct OpT {   // K x rows, rows contiguous (contraction index is the slow one)
     static constexpr bool TRANS = true;
     typedef typename TT<T>::Vec4 Vec4;
+    typedef int Ctx;               // unused for contraction-major operands
     const T* p; size_t ld; int rows; size_t bstride;
     DEVI void batch(int b) { p += (size_t)b * bstride; }
     DEVI Vec4 vec(int kk, int r, int kend) const {
@@ -72,6 +76,16 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(AOp A, BOp B, Epi ep
     constexpr int NPA = ((BM / 64) * PASS_K + NW - 1) / NW, NPB = ((BN / 64) * PASS_K + NW - 1) / NW;
     uint4 ra[CA], rb[CB];
     Vec4 ta[NPA][4], tb[NPB][4];
+    typename AOp::Ctx ca[CA];
+    typename BOp::Ctx cb[CB];
+    if constexpr (!AOp::TRANS) {
+#pragma unroll
+        for (int i = 0; i < CA; ++i) ca[i] = A.ctx(i0 + ((tid + NT * i) >> 3));
+    }
+    if constexpr (!BOp::TRANS) {
+#pragma unroll
+        for (int i = 0; i < CB; ++i) cb[i] = B.ctx(j0 + ((tid + NT * i) >> 3));
+    }
 
     // lane -> (row-block, k-block) inside one 64-row x 16-k transposing pass: a 16-lane LDS write
     // group covers 4 row-blocks x 4 k-blocks (bank-conflict free), a wave covers 16 x 4.
@@ -83,7 +97,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(AOp A, BOp B, Epi ep
 #pragma unroll
             for (int i = 0; i < CA; ++i) {
                 const int c = tid + NT * i;
-                if (BM * 8 % NT == 0 || c < BM * 8) ra[i] = A.chunk(i0 + (c >> 3), k0 + (c & 7) * EPC, ke);
+                if (BM * 8 % NT == 0 || c < BM * 8) ra[i] = A.chunk(ca[i], k0 + (c & 7) * EPC, ke);
             }
         } else {
 #pragma unroll
@@ -100,7 +114,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_kernel(AOp A, BOp B, Epi ep
 #pragma unroll
             for (int i = 0; i < CB; ++i) {
                 const int c = tid + NT * i;
-                if (BN * 8 % NT == 0 || c < BN * 8) rb[i] = B.chunk(j0 + (c >> 3), k0 + (c & 7) * EPC, ke);
+                if (BN * 8 % NT == 0 || c < BN * 8) rb[i] = B.chunk(cb[i], k0 + (c & 7) * EPC, ke);
             }
         } else {
 #pragma unroll

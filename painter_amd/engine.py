@@ -1,0 +1,248 @@
+"""Forward / backward orchestration of the Painter / SegGPT ViT hot path over the C ABI.
+
+This is the host-side mirror of Painter.forward_encoder / forward_decoder / forward_loss
+(Painter/models_painter.py:385-472) and SegGPT's variants (SegGPT/SegGPT_inference/models_seggpt.py:391-479):
+the control flow, buffer ownership and kernel order live here; every FLOP happens in libpainter_hip.so.
+Backward is written by hand -- nothing is delegated to torch autograd or ATen.
+
+Data layout in HBM (per rank):
+  residual stream x        fp32 [B'*L, D]           B' = 2B for blocks 0..merge_idx, B afterwards
+  GEMM operands / acts     T    (bf16 or fp32)      ln out [R,D], qkv [R,3D], attn out [R,D], fc1 pre/act [R,4D]
+  tap concat               T    [B*L, 4D]           LayerNorm of the 4 taps written straight into column slices
+  decoder image            T    NHWC [B, H, W, 64]  pixel shuffle fused into decoder_embed's epilogue
+  pred / loss              fp32 NCHW [B,3,H,W], [2]
+"""
+import torch
+
+from . import hostmath, ops
+from ._lib import EPI_BIAS, EPI_BIAS_F32, EPI_BIAS_RESID
+
+
+class HotPathConfig:
+    def __init__(self, img_size, patch_size, embed_dim, depth, num_heads, mlp_ratio, decoder_embed_dim,
+                 pretrain_img_size, pretrain_use_cls_token, use_rel_pos, ln_eps, loss_func, seggpt, drop_path_rate):
+        self.H, self.W = img_size
+        self.P = patch_size
+        self.D = embed_dim
+        self.depth = depth
+        self.heads = num_heads
+        self.hidden = int(embed_dim * mlp_ratio)
+        self.dec = decoder_embed_dim
+        self.Hp, self.Wp = self.H // patch_size, self.W // patch_size
+        self.L = self.Hp * self.Wp
+        self.src = pretrain_img_size // patch_size
+        self.cls = 1 if pretrain_use_cls_token else 0
+        self.use_rel_pos = use_rel_pos
+        self.ln_eps = ln_eps
+        self.loss_func = loss_func
+        self.seggpt = seggpt
+        self.merge_idx = 2                                   # models_painter.py:408
+        # models_painter.py:416 hard-codes [5, 11, 17, 23] (= depth/4*k - 1 at depth 24); generalised for other depths
+        self.taps = [5, 11, 17, 23] if depth == 24 else [depth // 4 * k - 1 for k in range(1, 5)]
+        self.dpr = hostmath.drop_path_rates(drop_path_rate, depth)
+        self.scale = (embed_dim // num_heads) ** -0.5
+        self.check()
+
+    def check(self):
+        """The HIP path's structural requirements (fail loudly, there is no fallback)."""
+        hd = self.D // self.heads
+        err = []
+        if hd != 64: err.append("head_dim must be 64 (got %d)" % hd)
+        if self.dec != 64: err.append("decoder_embed_dim must be 64 (got %d)" % self.dec)
+        if self.L % 32 or self.Hp % 4 or self.Wp % 4: err.append("token grid %dx%d must have Hp,Wp %% 4 == 0 and L %% 32 == 0" % (self.Hp, self.Wp))
+        if self.P % 8: err.append("patch_size must be a multiple of 8")
+        if self.D % 8 or self.hidden % 8: err.append("embed/hidden dims must be multiples of 8")
+        if not self.use_rel_pos: err.append("use_rel_pos=False is not built (the reference factories always enable it)")
+        if self.H != 2 * self.W: err.append("img_size must be (2W, W) (patchify asserts H == 2W, models_painter.py:361)")
+        if self.merge_idx >= self.depth or len(set(self.taps)) != 4 or self.taps[-1] != self.depth - 1:
+            err.append("depth %d incompatible with merge/tap schedule" % self.depth)
+        if err:
+            raise NotImplementedError("painter_amd HIP path: " + "; ".join(err))
+
+
+class _Saved:
+    pass
+
+
+class HotPath:
+    """Owns the per-module device constants and runs forward / backward."""
+
+    def __init__(self, cfg: HotPathConfig, compute_dtype):
+        self.cfg = cfg
+        self.T = compute_dtype
+        self._M = None
+        self._wcache = {}
+
+    # ------------------------------------------------------------------ constants / casts
+    def pos_operator(self, device):
+        if self._M is None or self._M.device != device:
+            c = self.cfg
+            self._M = torch.from_numpy(hostmath.abs_pos_operator(c.src, c.Hp, c.Wp)).to(device)
+        return self._M
+
+    def w(self, name, P):
+        """T-typed copy of a weight matrix (K9: cast once per optimizer step, keyed on the tensor version)."""
+        t = P[name]
+        if self.T == torch.float32:
+            return t.reshape(t.shape[0], -1)
+        key = (name, t.data_ptr())
+        ent = self._wcache.get(key)
+        if ent is None or ent[0] != t._version or ent[1].device != t.device:
+            buf = ent[1] if ent is not None and ent[1].device == t.device else torch.empty((t.shape[0], t.numel() // t.shape[0]), dtype=self.T, device=t.device)
+            ops.cast_bf16(t, buf)
+            self._wcache[key] = (t._version, buf)
+            return buf
+        return ent[1]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, P, imgs, tgts, mask_u8, valid, seg_type=None, merge_between_batch=-1, drop_scales=None, need_grad=True):
+        c, T = self.cfg, self.T
+        dev = imgs.device
+        B = imgs.shape[0]
+        L, D = c.L, c.D
+        S = _Saved()
+        S.B, S.need_grad = B, need_grad
+        S.imgs, S.tgts, S.mask, S.valid = imgs, tgts, mask_u8, valid
+        S.drop = drop_scales
+        M = self.pos_operator(dev)
+        pe = P["pos_embed"][0, c.cls:]
+        pos = ops.pos_fwd(M, pe, L, c.src * c.src, D)
+        x = ops.patch_embed_fwd(T, imgs, tgts, self.w("patch_embed.proj.weight", P), P["patch_embed.proj.bias"],
+                                P["mask_token"], P["segment_token_x"], P["segment_token_y"], pos, mask_u8,
+                                P.get("type_token_cls") if c.seggpt else None, P.get("type_token_ins") if c.seggpt else None,
+                                seg_type if c.seggpt else None, B, c.Hp, c.Wp, c.P, D)
+        concat = torch.empty((B * L, 4 * D), dtype=T, device=dev)
+        S.blocks, S.taps = [], []
+        Bc = 2 * B
+        for i in range(c.depth):
+            pre = "blocks.%d." % i
+            R = Bc * L
+            merge = 0
+            if c.seggpt and merge_between_batch >= 0 and i >= merge_between_batch:
+                merge = 1 if c.merge_idx >= i else 2
+            ds_a, ds_m = (None, None) if drop_scales is None else drop_scales[i]
+            ln1, mean1, rstd1 = ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], c.ln_eps, T)
+            qkv = ops.linear_fwd(ln1, self.w(pre + "attn.qkv.weight", P), P[pre + "attn.qkv.bias"], EPI_BIAS)
+            rcat = ops.relpos_pack(P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], c.Hp, c.Wp, T)
+            ao, lse = ops.attn_fwd(qkv, rcat, Bc, L, c.heads, c.Hp, c.Wp, c.scale)
+            if merge > 0:
+                if need_grad:
+                    raise NotImplementedError("SegGPT feature ensemble is inference-only (as in the reference: @torch.no_grad, seggpt_engine.py:26)")
+                a = ops.linear_fwd(ao, self.w(pre + "attn.proj.weight", P), P[pre + "attn.proj.bias"], EPI_BIAS_F32)
+                group = Bc // 2 if merge == 1 else Bc
+                x1 = ops.ensemble_resid(x, a, Bc, group, L, D)
+            else:
+                x1 = ops.linear_fwd(ao, self.w(pre + "attn.proj.weight", P), P[pre + "attn.proj.bias"], EPI_BIAS_RESID,
+                                    resid=x, rowscale=ds_a, rows_per_sample=L)
+            ln2, mean2, rstd2 = ops.layernorm_fwd(x1, P[pre + "norm2.weight"], P[pre + "norm2.bias"], c.ln_eps, T)
+            act, hpre = ops.linear_gelu(ln2, self.w(pre + "mlp.fc1.weight", P), P[pre + "mlp.fc1.bias"], need_pre=need_grad)
+            x2 = ops.linear_fwd(act, self.w(pre + "mlp.fc2.weight", P), P[pre + "mlp.fc2.bias"], EPI_BIAS_RESID,
+                                resid=x1, rowscale=ds_m, rows_per_sample=L)
+            if need_grad:
+                S.blocks.append((x, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc))
+            x = x2
+            if i == c.merge_idx:
+                Bc = B
+                x = ops.merge_fwd(x, B * L, D)
+            if i in c.taps:
+                k = c.taps.index(i)
+                _, mt, rt = ops.layernorm_fwd(x, P["norm.weight"], P["norm.bias"], c.ln_eps, T, out=concat[:, k * D:(k + 1) * D])
+                if need_grad:
+                    S.taps.append((x, mt, rt))
+        E = ops.linear_pixshuf(concat, self.w("decoder_embed.weight", P), P["decoder_embed.bias"], B, c.Hp, c.Wp, c.P, c.dec)
+        w3r, wf = ops.conv3x3_pack(P["decoder_pred.0.weight"], T)
+        w1 = P["decoder_pred.3.weight"].reshape(3, c.dec)
+        pred, y3 = ops.decoder_tail_fwd(E, w3r, P["decoder_pred.0.bias"], P["decoder_pred.1.weight"], P["decoder_pred.1.bias"],
+                                        w1, P["decoder_pred.3.bias"], 1e-6, save_y3=need_grad)
+        loss_out = ops.loss_fwd(pred, tgts, valid, mask_u8, c.P, ignore_rule=not c.seggpt,
+                                eps_den=0.0 if c.seggpt else 1e-2, kind=c.loss_func)
+        pred_patch = ops.patchify(pred, c.Hp, c.Wp, c.P)
+        if need_grad:
+            S.concat, S.E, S.y3, S.pred, S.loss_out, S.wf = concat, E, y3, pred, loss_out, wf
+        return loss_out, pred, pred_patch, S
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, P, S, dloss):
+        """-> {param name: fp32 grad}.  dloss: 0-d / [1] fp32 device tensor (may carry a GradScaler factor)."""
+        c, T = self.cfg, self.T
+        B, L, D = S.B, c.L, c.D
+        dev = S.imgs.device
+        G = {}
+        dpred = ops.loss_bwd(S.pred, S.tgts, S.valid, S.mask, dloss, S.loss_out, c.P, c.loss_func)
+        w1 = P["decoder_pred.3.weight"].reshape(3, c.dec)
+        dy3, tg = ops.decoder_tail_bwd_pointwise(dpred, S.y3, P["decoder_pred.1.weight"], P["decoder_pred.1.bias"], w1, 1e-6)
+        G["decoder_pred.1.weight"] = tg[0:64]
+        G["decoder_pred.1.bias"] = tg[64:128]
+        G["decoder_pred.3.weight"] = tg[128:320].reshape(3, c.dec, 1, 1)
+        G["decoder_pred.3.bias"] = tg[320:323]
+        npix = B * c.H * c.W
+        G["decoder_pred.0.weight"] = ops.conv3x3_wgrad(dy3, S.E)
+        G["decoder_pred.0.bias"] = ops.colsum(dy3.view(npix, c.dec))
+        dE = ops.conv3x3_dgrad_unshuffle(dy3, S.wf, B, c.Hp, c.Wp, c.P)
+        del dy3
+        G["decoder_embed.weight"] = ops.linear_wgrad(dE, S.concat)
+        G["decoder_embed.bias"] = ops.colsum(dE)
+        dconcat = ops.linear_dgrad(dE, self.w("decoder_embed.weight", P))
+        del dE
+        dnorm = None
+        dx = None
+        for i in reversed(range(c.depth)):
+            pre = "blocks.%d." % i
+            x0, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc = S.blocks[i]
+            S.blocks[i] = None
+            R = Bc * L
+            ds_a, ds_m = (None, None) if S.drop is None else S.drop[i]
+            if i in c.taps:
+                k = c.taps.index(i)
+                xt, mt, rt = S.taps[k]
+                dx, gb = ops.layernorm_bwd(dconcat[:, k * D:(k + 1) * D], xt, mt, rt, P["norm.weight"], dres=dx, dx=dx)
+                dnorm = gb if dnorm is None else _add_(dnorm, gb)
+            if i == c.merge_idx:
+                dx, dyT = ops.merge_bwd(T, dx, ds_m, L, B * L, D)
+            else:
+                dyT = ops.scale_cast(T, dx, ds_m, L)
+            # ---- MLP branch: x2 = x1 + s_m * fc2(gelu(fc1(LN2(x1))))
+            G[pre + "mlp.fc2.weight"] = ops.linear_wgrad(dyT, act)
+            G[pre + "mlp.fc2.bias"] = ops.colsum(dyT)
+            dpre = ops.linear_dgrad(dyT, self.w(pre + "mlp.fc2.weight", P), pre=hpre)
+            G[pre + "mlp.fc1.weight"] = ops.linear_wgrad(dpre, ln2)
+            G[pre + "mlp.fc1.bias"] = ops.colsum(dpre)
+            dln2 = ops.linear_dgrad(dpre, self.w(pre + "mlp.fc1.weight", P))
+            del dpre
+            dx, gb = ops.layernorm_bwd(dln2, x1, mean2, rstd2, P[pre + "norm2.weight"], dres=dx, dx=dx, dxT=dyT,
+                                       rowscale=ds_a, rows_per_sample=L)
+            G[pre + "norm2.weight"], G[pre + "norm2.bias"] = gb[0], gb[1]
+            # ---- attention branch: x1 = x0 + s_a * proj(attn(LN1(x0)))
+            G[pre + "attn.proj.weight"] = ops.linear_wgrad(dyT, ao)
+            G[pre + "attn.proj.bias"] = ops.colsum(dyT)
+            dao = ops.linear_dgrad(dyT, self.w(pre + "attn.proj.weight", P), out=dln2)
+            rcatT = ops.relpos_pack_t(P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], c.Hp, c.Wp, T)
+            dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, ao, dao, lse, Bc, L, c.heads, c.Hp, c.Wp, c.scale)
+            nh, nw = 2 * c.Hp - 1, 2 * c.Wp - 1
+            G[pre + "attn.rel_pos_h"] = drcat[:nh]
+            G[pre + "attn.rel_pos_w"] = drcat[nh:nh + nw]
+            G[pre + "attn.qkv.weight"] = ops.linear_wgrad(dqkv, ln1)
+            G[pre + "attn.qkv.bias"] = ops.colsum(dqkv)
+            dln1 = ops.linear_dgrad(dqkv, self.w(pre + "attn.qkv.weight", P), out=dao)
+            del dqkv
+            dx, gb = ops.layernorm_bwd(dln1, x0, mean1, rstd1, P[pre + "norm1.weight"], dres=dx, dx=dx)
+            G[pre + "norm1.weight"], G[pre + "norm1.bias"] = gb[0], gb[1]
+        G["norm.weight"], G["norm.bias"] = dnorm[0], dnorm[1]
+        # ---- token assembly + patch embed
+        dpe, sums = ops.tokens_bwd(T, dx, S.mask, B, L, D)
+        G["patch_embed.proj.weight"] = ops.patch_embed_wgrad(dpe, S.imgs, S.tgts, B, c.Hp, c.Wp, c.P, D).view(D, 3, c.P, c.P)
+        G["patch_embed.proj.bias"] = ops.colsum(dpe)
+        dposemb = torch.zeros_like(P["pos_embed"])
+        ops.pos_bwd(self.pos_operator(dev), sums[0], sums[1], dposemb[0, c.cls:], L, c.src * c.src, D)
+        G["pos_embed"] = dposemb
+        G["segment_token_x"] = ops.colsum(sums[0]).view(1, 1, 1, D)
+        G["segment_token_y"] = ops.colsum(sums[1]).view(1, 1, 1, D)
+        G["mask_token"] = ops.colsum(sums[2]).view(1, 1, 1, D)
+        return G
+
+
+def _add_(a, b):
+    """a += b for two small fp32 device tensors through the slab reducer (keeps arithmetic inside the library)."""
+    from ._lib import check, lib
+    check(lib.pa_slab_reduce(b.data_ptr(), a.data_ptr(), a.numel(), 1, a.numel(), 1, ops.stream()), "pa_slab_reduce")
+    return a

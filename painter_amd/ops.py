@@ -155,3 +155,174 @@ def attn_fwd(qkv, rcat, batch, L, heads, Hp, Wp, scale):
     check(lib.pa_attn_fwd(code(T), p(qkv), qkv.stride(0), p(rcat), p(out), out.stride(0), p(lse), batch, L, heads, Hp, Wp,
                           float(scale), stream()), "pa_attn_fwd")
     return out, lse
+
+
+def relpos_pack_t(rel_pos_h, rel_pos_w, Hp, Wp, dtype):
+    nrp = lib.pa_relpos_rows_padded(Hp, Wp)
+    rcatT = torch.empty((64, nrp), dtype=dtype, device=rel_pos_h.device)
+    check(lib.pa_relpos_pack_t(code(dtype), p(rel_pos_h), p(rel_pos_w), p(rcatT), Hp, Wp, stream()), "pa_relpos_pack_t")
+    return rcatT
+
+
+def attn_bwd(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale):
+    """-> (dqkv T [batch*L, 3*heads*64], drcat f32 [NRP, 64])."""
+    T = qkv.dtype
+    dev = qkv.device
+    nrp = rcat.shape[0]
+    delta = torch.empty((batch * heads, L), dtype=torch.float32, device=dev)
+    check(lib.pa_attn_bwd_delta(code(T), p(out), out.stride(0), p(dout), dout.stride(0), p(delta), batch, L, heads,
+                                stream()), "pa_attn_bwd_delta")
+    dqkv = torch.empty_like(qkv)
+    dG = torch.empty((batch * L, heads * nrp), dtype=T, device=dev)
+    aux = workspace(lib.pa_attn_bwd_aux_bytes(batch, L, heads, Hp, Wp), dev, slot=1)
+    check(lib.pa_attn_bwd(code(T), p(qkv), qkv.stride(0), p(rcat), p(rcatT), p(dout), dout.stride(0), p(lse), p(delta),
+                          p(dqkv), p(dG), p(aux), batch, L, heads, Hp, Wp, float(scale), stream()), "pa_attn_bwd")
+    drcat = torch.empty((nrp, 64), dtype=torch.float32, device=dev)
+    ws = workspace(lib.pa_attn_bwd_relpos_workspace_bytes(code(T), batch, L, heads, Hp, Wp), dev)
+    check(lib.pa_attn_bwd_relpos(code(T), p(dG), p(qkv), qkv.stride(0), p(drcat), p(ws), batch, L, heads, Hp, Wp,
+                                 stream()), "pa_attn_bwd_relpos")
+    return dqkv, drcat
+
+
+# ------------------------------------------------------------------------------------------- tokens / pos / merge
+def cast_bf16(x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib.pa_cast_bf16(p(x), p(out), x.numel(), stream()), "pa_cast_bf16")
+    return out
+
+
+def pos_fwd(M, pe, L, S, D):
+    pos = torch.empty((L, D), dtype=torch.float32, device=pe.device)
+    check(lib.pa_pos_fwd(p(M), p(pe), p(pos), L, S, D, stream()), "pa_pos_fwd")
+    return pos
+
+
+def pos_bwd(M, gx, gy, dpe, L, S, D):
+    check(lib.pa_pos_bwd(p(M), p(gx), p(gy), p(dpe), L, S, D, stream()), "pa_pos_bwd")
+
+
+def patch_embed_fwd(T, imgs, tgts, w, bias, mask_token, seg_x, seg_y, pos, mask_u8, type_cls, type_ins, seg_type,
+                    batch, Hp, Wp, P, D):
+    tokens = torch.empty((2 * batch * Hp * Wp, D), dtype=torch.float32, device=imgs.device)
+    mbs = 0 if mask_u8.shape[0] == 1 else mask_u8.stride(0)
+    check(lib.pa_patch_embed_fwd(code(T), p(imgs), p(tgts), p(w), p(bias), p(mask_token), p(seg_x), p(seg_y), p(pos),
+                                 p(mask_u8), mbs, p(type_cls), p(type_ins), p(seg_type), p(tokens), batch, Hp, Wp, P, D,
+                                 stream()), "pa_patch_embed_fwd")
+    return tokens
+
+
+def patch_embed_wgrad(dpe, imgs, tgts, batch, Hp, Wp, P, D):
+    dw = torch.empty((D, 3 * P * P), dtype=torch.float32, device=dpe.device)
+    ws = workspace(lib.pa_patch_embed_wgrad_workspace_bytes(D, P), dpe.device)
+    check(lib.pa_patch_embed_wgrad(code(dpe.dtype), p(dpe), p(imgs), p(tgts), p(dw), p(ws), batch, Hp, Wp, P, D, stream()),
+          "pa_patch_embed_wgrad")
+    return dw
+
+
+def tokens_bwd(T, dx0, mask_u8, batch, L, D):
+    dpe = torch.empty((2 * batch * L, D), dtype=T, device=dx0.device)
+    sums = torch.empty((3, L, D), dtype=torch.float32, device=dx0.device)
+    mbs = 0 if mask_u8.shape[0] == 1 else mask_u8.stride(0)
+    check(lib.pa_tokens_bwd(code(T), p(dx0), p(mask_u8), mbs, p(dpe), p(sums), batch, L, D, stream()), "pa_tokens_bwd")
+    return dpe, sums
+
+
+def merge_fwd(x, rows_out, D):
+    out = torch.empty((rows_out, D), dtype=torch.float32, device=x.device)
+    check(lib.pa_merge_fwd(p(x), p(out), rows_out * D, stream()), "pa_merge_fwd")
+    return out
+
+
+def merge_bwd(T, dmerged, rowscale, rps, rows_half, D):
+    dx = torch.empty((2 * rows_half, D), dtype=torch.float32, device=dmerged.device)
+    dxT = torch.empty((2 * rows_half, D), dtype=T, device=dmerged.device)
+    check(lib.pa_merge_bwd(code(T), p(dmerged), p(dx), p(dxT), p(rowscale), rps, rows_half, D, stream()), "pa_merge_bwd")
+    return dx, dxT
+
+
+def scale_cast(T, x, rowscale, rps, out=None):
+    rows, D = x.shape
+    if out is None:
+        out = torch.empty((rows, D), dtype=T, device=x.device)
+    check(lib.pa_scale_cast(code(T), p(x), p(out), p(rowscale), rps, rows, D, stream()), "pa_scale_cast")
+    return out
+
+
+def ensemble_resid(x0, a, batch, group, L, D):
+    x1 = torch.empty_like(x0)
+    check(lib.pa_ensemble_resid(p(x0), p(a), p(x1), batch, group, L, D, stream()), "pa_ensemble_resid")
+    return x1
+
+
+# ------------------------------------------------------------------------------------------- decoder tail / loss
+def conv3x3_pack(w3, T):
+    w3r = torch.empty((64, 9, 64), dtype=T, device=w3.device)
+    wf = torch.empty((64, 9, 64), dtype=T, device=w3.device)
+    check(lib.pa_conv3x3_pack(code(T), p(w3), p(w3r), p(wf), stream()), "pa_conv3x3_pack")
+    return w3r, wf
+
+
+def decoder_tail_fwd(x_nhwc, w3r, b3, gamma, beta, w1, b1, eps, save_y3=True):
+    B, Hi, Wi, C = x_nhwc.shape
+    T = x_nhwc.dtype
+    y3 = torch.empty((B, Hi, Wi, C), dtype=T, device=x_nhwc.device) if save_y3 else None
+    pred = torch.empty((B, 3, Hi, Wi), dtype=torch.float32, device=x_nhwc.device)
+    check(lib.pa_decoder_tail_fwd(code(T), p(x_nhwc), p(w3r), p(b3), p(gamma), p(beta), p(w1), p(b1), p(y3), p(pred), B, Hi, Wi,
+                                  float(eps), stream()), "pa_decoder_tail_fwd")
+    return pred, y3
+
+
+def decoder_tail_bwd_pointwise(dpred, y3, gamma, beta, w1, eps):
+    B, Hi, Wi, C = y3.shape
+    T = y3.dtype
+    dy3 = torch.empty_like(y3)
+    grads = torch.empty((324,), dtype=torch.float32, device=y3.device)
+    ws = workspace(lib.pa_decoder_tail_bwd_workspace_bytes(B, Hi, Wi), y3.device)
+    check(lib.pa_decoder_tail_bwd_pointwise(code(T), p(dpred), p(y3), p(gamma), p(beta), p(w1), p(dy3), p(grads), p(ws), B, Hi, Wi,
+                                            float(eps), stream()), "pa_decoder_tail_bwd_pointwise")
+    return dy3, grads
+
+
+def conv3x3_dgrad_unshuffle(dy3, wf, batch, Hp, Wp, P):
+    T = dy3.dtype
+    dE = torch.empty((batch * Hp * Wp, P * P * 64), dtype=T, device=dy3.device)
+    check(lib.pa_conv3x3_dgrad_unshuffle(code(T), p(dy3), p(wf), p(dE), batch, Hp, Wp, P, stream()), "pa_conv3x3_dgrad_unshuffle")
+    return dE
+
+
+def conv3x3_wgrad(dy3, x_nhwc):
+    B, Hi, Wi, C = x_nhwc.shape
+    dw = torch.empty((64, 64, 3, 3), dtype=torch.float32, device=dy3.device)
+    ws = workspace(lib.pa_conv3x3_wgrad_workspace_bytes(B, Hi, Wi), dy3.device)
+    check(lib.pa_conv3x3_wgrad(code(dy3.dtype), p(dy3), p(x_nhwc), p(dw), p(ws), B, Hi, Wi, stream()), "pa_conv3x3_wgrad")
+    return dw
+
+
+LOSS_KINDS = {"smoothl1": 0, "l1": 1, "l2": 2, "l1l2": 3}
+
+
+def loss_fwd(pred, tgts, valid, mask_u8, P, ignore_rule, eps_den, kind, beta=0.01):
+    B, _, Hi, Wi = pred.shape
+    out = torch.empty((2,), dtype=torch.float32, device=pred.device)
+    ws = workspace(lib.pa_loss_workspace_bytes(B, Hi, Wi), pred.device)
+    mbs = 0 if mask_u8.shape[0] == 1 else mask_u8.stride(0)
+    check(lib.pa_loss_fwd(p(pred), p(tgts), p(valid), p(mask_u8), mbs, p(out), p(ws), B, Hi, Wi, P, int(ignore_rule),
+                          float(eps_den), LOSS_KINDS[kind], float(beta), stream()), "pa_loss_fwd")
+    return out
+
+
+def loss_bwd(pred, tgts, valid, mask_u8, dloss, loss_out, P, kind, beta=0.01):
+    B, _, Hi, Wi = pred.shape
+    dpred = torch.empty_like(pred)
+    mbs = 0 if mask_u8.shape[0] == 1 else mask_u8.stride(0)
+    check(lib.pa_loss_bwd(p(pred), p(tgts), p(valid), p(mask_u8), mbs, p(dloss), p(loss_out), p(dpred), B, Hi, Wi, P,
+                          LOSS_KINDS[kind], float(beta), stream()), "pa_loss_bwd")
+    return dpred
+
+
+def patchify(pred, Hp, Wp, P):
+    B = pred.shape[0]
+    out = torch.empty((B, Hp * Wp, P * P * 3), dtype=torch.float32, device=pred.device)
+    check(lib.pa_patchify(p(pred), p(out), B, Hp, Wp, P, stream()), "pa_patchify")
+    return out

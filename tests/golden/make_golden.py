@@ -155,9 +155,13 @@ def case_vit_large(out, prefix):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also generate the ViT-L 896x448 fixture")
+    ap.add_argument("--small", action="store_true", help="only (re)generate the small HIP-path fixture")
+    ap.add_argument("--skip-tiny", action="store_true")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
 
+    if args.skip_tiny or args.small:
+        return _rest(args)
     out = {}
     tiny = O.tiny_config()
     case_painter(tiny, out, "painter_half/", batch=2, mask_kind="half")
@@ -173,6 +177,21 @@ def main():
     case_seggpt(tseg, out, "seggpt_n4_merge/", 4, 0, "semantic", seed_p=4, seed_x=77)
     np.savez_compressed(os.path.join(HERE, "seggpt_tiny.npz"), **out)
     print("seggpt_tiny.npz", {k: v for k, v in out.items() if k.endswith("loss")})
+
+    _rest(args)
+
+
+def _rest(args):
+    if args.small or args.full:
+        out = {}
+        small = O.small_config()
+        case_painter(small, out, "painter_rand/", batch=2, mask_kind="random", seed_p=11, seed_x=21)
+        case_painter(small, out, "painter_train/", batch=2, mask_kind="half", seed_p=12, seed_x=22, train_mode=True)
+        ssmall = O.small_config(seggpt=True)
+        case_seggpt(ssmall, out, "seggpt_n3_merge/", 3, 0, "instance", seed_p=13, seed_x=23)
+        case_seggpt(ssmall, out, "seggpt_n1/", 1, -1, "semantic", seed_p=13, seed_x=24)
+        np.savez_compressed(os.path.join(HERE, "painter_small.npz"), **out)
+        print("painter_small.npz", {k: v for k, v in out.items() if k.endswith("loss")})
 
     if args.full:
         out = {}

@@ -151,6 +151,34 @@ def test_attn_fwd(T, B, H, Hp, Wp):
     assert e_o < (2e-5 if T == torch.float32 else 2e-2), (e_o, e_l)
 
 
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Hp,Wp", [(1, 2, 8, 4), (2, 2, 56, 28), (3, 1, 16, 8)])
+def test_attn_bwd(T, B, H, Hp, Wp):
+    L = Hp * Wp
+    nh, nw = 2 * Hp - 1, 2 * Wp - 1
+    qkv = gen((B * L, 3 * H * 64), 1, 1.0, T)
+    rel_h = gen((nh, 64), 2, 0.2)
+    rel_w = gen((nw, 64), 3, 0.2)
+    dout = gen((B * L, H * 64), 4, 1.0, T)
+    rcat = ops.relpos_pack(rel_h, rel_w, Hp, Wp, T)
+    rcatT = ops.relpos_pack_t(rel_h, rel_w, Hp, Wp, T)
+    assert torch.equal(rcatT.t().contiguous(), rcat)
+    out, lse = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125)
+    dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125)
+    q64 = qkv.double().clone().requires_grad_(True)
+    rh64 = rcat[:nh].double().clone().requires_grad_(True)
+    rw64 = rcat[nh:nh + nw].double().clone().requires_grad_(True)
+    ref, _ = attn_reference(q64, rh64, rw64, B, L, H, Hp, Wp, 0.125)
+    ref.backward(dout.double())
+    D = H * 64
+    tol = 5e-5 if T == torch.float32 else 3e-2
+    errs = dict(dq=relerr(dqkv[:, :D].float(), q64.grad[:, :D]), dk=relerr(dqkv[:, D:2 * D].float(), q64.grad[:, D:2 * D]),
+                dv=relerr(dqkv[:, 2 * D:].float(), q64.grad[:, 2 * D:]), drh=relerr(drcat[:nh], rh64.grad),
+                drw=relerr(drcat[nh:nh + nw], rw64.grad))
+    assert max(errs.values()) < tol, errs
+    assert float(drcat[nh + nw:].abs().max()) == 0.0 if drcat.shape[0] > nh + nw else True
+
+
 def test_attn_fwd_spiked_key_online_softmax():
     """Force large running-max jumps late in the key stream (rule: a data-dependent rescale needs its own test)."""
     B, H, Hp, Wp = 1, 1, 16, 8

@@ -1,0 +1,170 @@
+"""Whole-model GPU parity: the HIP path (through the drop-in nn.Module and the C ABI) against
+  (1) golden vectors produced by the UNMODIFIED reference (tests/golden/*.npz) and
+  (2) the CPU oracle on the same seeded inputs.
+fp32 build: the north-star gate, 1e-3 relative (we assert tighter); bf16 build: loss to 2e-3, pred against the
+reference's own bf16-autocast deviation (~1e-2)."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import painter_oracle as O
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from painter_amd import models_painter, models_seggpt
+
+
+def build(cfg, seed, dtype, train=False):
+    cls = models_seggpt.SegGPT if cfg.seggpt else models_painter.Painter
+    m = cls(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+            drop_path_rate=0.1, window_size=14, qkv_bias=True, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+            window_block_indexes=([0, 1], [3, 4]), residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat",
+            decoder_embed_dim=cfg.decoder_embed_dim, loss_func="smoothl1", compute_dtype=dtype)
+    P = O.random_params(cfg, seed)
+    missing = m.load_state_dict(P, strict=True)
+    m = m.cuda()
+    m.train(train)
+    return m, P
+
+
+def run_painter(m, cfg, batch, seed_x, mask_kind, backward=True):
+    imgs, tgts, mask, valid = O.synthetic_batch(cfg, batch, seed_x, mask_kind)
+    valid_d = valid.cuda()
+    for p in m.parameters():
+        p.grad = None
+    loss, pred, mo = m(imgs.cuda(), tgts.cuda(), bool_masked_pos=mask.reshape(batch, *cfg.grid).cuda(), valid=valid_d)
+    if backward:
+        loss.backward()
+    torch.cuda.synchronize()
+    return loss, pred, mo, valid_d
+
+
+def test_small_fp32_vs_reference_golden_and_oracle():
+    fx = G.load("painter_small.npz")
+    case, cfg = "painter_rand/", O.small_config()
+    m, P = build(cfg, 11, "fp32")
+    loss, pred, mo, valid_d = run_painter(m, cfg, 2, 21, "random")
+    ref_loss = float(fx[case + "loss"])
+    assert abs(loss.item() - ref_loss) < 1e-4 * abs(ref_loss), (loss.item(), ref_loss)
+    e = G.rel_err(pred.cpu(), fx[case + "pred"])
+    assert e < 2e-4, e
+    assert np.array_equal(mo.cpu().numpy(), fx[case + "mask_out"])
+    assert valid_d.double().sum().item() == float(fx[case + "valid_out_sum"])
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-3, 1e-3, 1e-3)
+    # same inputs through the oracle at run time (no fixture): forward + every gradient tensor
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    imgs, tgts, mask, valid = O.synthetic_batch(cfg, 2, 21, "random")
+    lo, po, _ = O.forward(Pg, cfg, imgs, tgts, mask, valid)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-4 * abs(lo.item())
+    assert G.rel_err(pred.cpu(), po.detach()) < 2e-4
+    worst = max((G.rel_fro(p.grad.cpu(), Pg[n].grad), n) for n, p in m.named_parameters())
+    assert worst[0] < 1e-3, worst
+
+
+def test_small_train_mode_droppath_vs_reference_golden():
+    """DropPath with the reference's recorded per-sample factors (timm 0.3.2 semantics), fwd + bwd."""
+    fx = G.load("painter_small.npz")
+    case, cfg = "painter_train/", O.small_config()
+    m, _ = build(cfg, 12, "fp32", train=True)
+    flat = torch.from_numpy(fx[case + "drop_scales_flat"])
+    chunks = list(torch.split(flat, [int(x) for x in fx[case + "drop_scales_len"]]))
+    m._drop_override = [(None, None)] + [(chunks[2 * i].cuda().contiguous(), chunks[2 * i + 1].cuda().contiguous()) for i in range(cfg.depth - 1)]
+    loss, pred, _, _ = run_painter(m, cfg, 2, 22, "half")
+    ref_loss = float(fx[case + "loss"])
+    assert abs(loss.item() - ref_loss) < 1e-4 * abs(ref_loss), (loss.item(), ref_loss)
+    assert G.rel_err(pred.cpu(), fx[case + "pred"]) < 2e-4
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-3, 1e-3, 1e-3)
+    # statistical check of the module's own sampler: factors are 0 or 1/keep, never applied to block 0
+    m._drop_override = None
+    ds = m._drop_scales(64, torch.device("cuda"))
+    assert ds[0] == (None, None) and ds[1][0].shape == (128,) and ds[5][0].shape == (64,)
+    keep = 1.0 - m.blocks[23].drop_path_prob
+    vals = torch.unique(ds[23][0].cpu())
+    assert all(abs(v) < 1e-6 or abs(v - 1.0 / keep) < 1e-5 for v in vals.tolist())
+
+
+def test_small_bf16_vs_reference_golden():
+    fx = G.load("painter_small.npz")
+    case, cfg = "painter_rand/", O.small_config()
+    m, _ = build(cfg, 11, "bf16")
+    loss, pred, _, _ = run_painter(m, cfg, 2, 21, "random")
+    ref_loss = float(fx[case + "loss"])
+    assert abs(loss.item() - ref_loss) < 2e-3 * abs(ref_loss), (loss.item(), ref_loss)
+    assert G.rel_fro(pred.cpu(), fx[case + "pred"]) < 3e-2
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 8e-2, 5e-2, 8e-2)
+
+
+@pytest.mark.parametrize("case,n,merge,seg,seed_x", [("seggpt_n3_merge/", 3, 0, "instance", 23), ("seggpt_n1/", 1, -1, "semantic", 24)])
+def test_small_seggpt_inference_vs_reference_golden(case, n, merge, seg, seed_x):
+    fx = G.load("painter_small.npz")
+    cfg = O.small_config(seggpt=True)
+    m, _ = build(cfg, 13, "fp32")
+    imgs, tgts, _, valid = O.synthetic_batch(cfg, n, seed_x, "half")
+    L = cfg.grid[0] * cfg.grid[1]
+    mask = torch.zeros(1, L)
+    mask[:, L // 2:] = 1
+    seg_type = torch.ones(n, 1) if seg == "instance" else torch.zeros(n, 1)
+    with torch.no_grad():
+        loss, pred, mo = m(imgs.cuda(), tgts.cuda(), mask.cuda(), valid.cuda(), seg_type.cuda(), merge)
+    ref_loss = float(fx[case + "loss"])
+    assert abs(loss.item() - ref_loss) < 1e-4 * abs(ref_loss), (loss.item(), ref_loss)
+    assert G.rel_err(pred.cpu(), fx[case + "pred"]) < 2e-4
+    assert mo.shape == (1, L) and mo.dtype == torch.bool
+
+
+def test_ignore_rule_and_determinism():
+    cfg = O.small_config()
+    m, P = build(cfg, 1, "bf16")
+    imgs, tgts, mask, valid = O.synthetic_batch(cfg, 2, 3, "half")
+    mean = torch.tensor(O.IMAGENET_MEAN)[None, :, None, None]
+    std = torch.tensor(O.IMAGENET_STD)[None, :, None, None]
+    tgts[1] = ((torch.zeros(1, 3, 128, 64) - mean) / std)[0]
+    v1 = valid.clone().cuda()
+    l1, p1, _ = m(imgs.cuda(), tgts.cuda(), mask.cuda(), v1)
+    l1.backward()
+    g1 = [p.grad.clone() for p in m.parameters()]
+    assert v1[0].min() == 1.0 and v1[1].max() == 0.0                 # in-place mutation, models_painter.py:448
+    vo = valid.clone()
+    lo, _, _ = O.forward(P, cfg, imgs, tgts, mask, vo)
+    assert abs(l1.item() - lo.item()) < 3e-3 * abs(lo.item())
+    for p in m.parameters():
+        p.grad = None
+    v2 = valid.clone().cuda()
+    l2, p2, _ = m(imgs.cuda(), tgts.cuda(), mask.cuda(), v2)
+    l2.backward()
+    assert torch.equal(l1, l2) and torch.equal(p1, p2)                # same input twice -> bit-identical
+    assert all(torch.equal(a, p.grad) for a, p in zip(g1, m.parameters()))
+
+
+def test_vit_large_fp32_vs_reference_golden():
+    """BASELINE configs[0]/[1] shape (896x448, ViT-L), B=1, against the reference's own CPU fp32 output."""
+    fx = G.load("painter_vitl.npz")
+    case, cfg = "vitl_b1/", O.vit_large_config()
+    m, _ = build(cfg, 1, "fp32")
+    loss, pred, _, _ = run_painter(m, cfg, 1, 1234, "random")
+    ref_loss = float(fx[case + "loss"])
+    assert abs(loss.item() - ref_loss) < 1e-4 * abs(ref_loss), (loss.item(), ref_loss)
+    flat = pred.reshape(-1).cpu()
+    stride = int(fx[case + "pred_stride"])
+    assert G.rel_err(flat[::stride], fx[case + "pred_sample"]) < 1e-3
+    assert abs(float(flat.double().norm()) - float(fx[case + "pred_norm"])) < 1e-4 * float(fx[case + "pred_norm"])
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-3, 1e-3, 1e-3)
+
+
+def test_vit_large_bf16_loss_and_pred_yardstick():
+    fx = G.load("painter_vitl.npz")
+    case, cfg = "vitl_b1/", O.vit_large_config()
+    m, _ = build(cfg, 1, "bf16")
+    loss, pred, _, _ = run_painter(m, cfg, 1, 1234, "random")
+    ref_loss = float(fx[case + "loss"])
+    assert abs(loss.item() - ref_loss) < 2e-3 * abs(ref_loss), (loss.item(), ref_loss)
+    flat = pred.reshape(-1).cpu()
+    stride = int(fx[case + "pred_stride"])
+    assert G.rel_fro(flat[::stride], fx[case + "pred_sample"]) < 3e-2      # reference's own bf16 deviation: 1e-2
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-1, 5e-2, 1e-1)
