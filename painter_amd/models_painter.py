@@ -110,7 +110,7 @@ class _HotPathFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hp, names, opts, imgs, tgts, mask_u8, valid, seg_type, *params):
         P = dict(zip(names, params))
-        need = any(ctx.needs_input_grad[8:])          # nothing is saved for inference / no_grad calls
+        need = bool(opts.get("need_grad", True)) and any(ctx.needs_input_grad[8:])   # nothing is saved for inference
         loss_out, pred, pred_patch, S = hp.forward(P, imgs, tgts, mask_u8, valid, seg_type, opts.get("merge", -1),
                                                    opts.get("drop"), need_grad=need)
         ctx.hp, ctx.S, ctx.names = hp, S, names
@@ -291,7 +291,7 @@ class Painter(nn.Module):
             assert st.numel() == B
         names, params = zip(*self.named_parameters())
         drop = self._drop_override if getattr(self, "_drop_override", None) is not None else self._drop_scales(B, imgs.device)
-        opts = {"merge": merge_between_batch, "drop": drop, "grad_sync": self.grad_sync}
+        opts = {"merge": merge_between_batch, "drop": drop, "grad_sync": self.grad_sync, "need_grad": torch.is_grad_enabled()}
         loss, pred_patch = _HotPathFn.apply(self._hot, names, opts, imgs_c, tgts_c, mask_u8, valid_c, st, *params)
         if not in_place and valid.shape == valid_c.shape:
             valid.copy_(valid_c)          # the reference mutates the caller's `valid` (models_painter.py:448)
