@@ -162,8 +162,9 @@ class HotPath:
         return loss_out, pred, pred_patch, S
 
     # ------------------------------------------------------------------ backward
-    def backward(self, P, S, dloss):
-        """-> {param name: fp32 grad}.  dloss: 0-d / [1] fp32 device tensor (may carry a GradScaler factor)."""
+    def backward(self, P, S, dloss, sync=None):
+        """-> {param name: fp32 grad}.  dloss: 0-d / [1] fp32 device tensor (may carry a GradScaler factor).
+        sync: optional painter_amd.parallel.GradSync; buckets are handed over as soon as they are enqueued."""
         c, T = self.cfg, self.T
         B, L, D = S.B, c.L, c.D
         dev = S.imgs.device
@@ -184,6 +185,9 @@ class HotPath:
         G["decoder_embed.bias"] = ops.colsum(dE)
         dconcat = ops.linear_dgrad(dE, self.w("decoder_embed.weight", P))
         del dE
+        if sync is not None:
+            sync.ready(G, ["decoder_embed.weight", "decoder_embed.bias"])
+            sync.ready(G, [n for n in G if n.startswith("decoder_pred.")])
         dnorm = None
         dx = None
         for i in reversed(range(c.depth)):
@@ -227,6 +231,8 @@ class HotPath:
             del dqkv
             dx, gb = ops.layernorm_bwd(dln1, x0, mean1, rstd1, P[pre + "norm1.weight"], dres=dx, dx=dx)
             G[pre + "norm1.weight"], G[pre + "norm1.bias"] = gb[0], gb[1]
+            if sync is not None:
+                sync.ready(G, [n for n in G if n.startswith(pre)])
         G["norm.weight"], G["norm.bias"] = dnorm[0], dnorm[1]
         # ---- token assembly + patch embed
         dpe, sums = ops.tokens_bwd(T, dx, S.mask, B, L, D)
@@ -238,6 +244,10 @@ class HotPath:
         G["segment_token_x"] = ops.colsum(sums[0]).view(1, 1, 1, D)
         G["segment_token_y"] = ops.colsum(sums[1]).view(1, 1, 1, D)
         G["mask_token"] = ops.colsum(sums[2]).view(1, 1, 1, D)
+        if sync is not None:
+            sync.ready(G, ["norm.weight", "norm.bias", "patch_embed.proj.weight", "patch_embed.proj.bias", "pos_embed",
+                           "segment_token_x", "segment_token_y", "mask_token"])
+            sync.finish()
         return G
 
 

@@ -128,10 +128,8 @@ class _HotPathFn(torch.autograd.Function):
         params = ctx.saved_tensors
         P = dict(zip(ctx.names, params))
         dl = dloss.detach().to(torch.float32).reshape(1).contiguous()
-        G = ctx.hp.backward(P, ctx.S, dl)
+        G = ctx.hp.backward(P, ctx.S, dl, sync=ctx.grad_sync)
         ctx.S = None
-        if ctx.grad_sync is not None:
-            G = ctx.grad_sync(G)
         grads = []
         for n, p_ in zip(ctx.names, params):
             g = G.get(n)

@@ -1,0 +1,79 @@
+"""Data-parallel gradient exchange for the hot path (replaces the DDP reducer installed at
+Painter/main_train.py:340).
+
+One process per GPU, `torch.distributed` backend "nccl" (= RCCL on ROCm, xGMI between the 8 GPUs of a node).  The
+path shards by samples, so the only exchange is the gradient all-reduce: `GradSync` is called by the engine's
+backward as soon as a bucket of parameter gradients has been ENQUEUED (decoder head first, then blocks 23 -> 0, then
+the patch/token parameters), flattens the bucket into one contiguous fp32 message and starts an asynchronous
+all-reduce(AVG).  RCCL runs it on its own stream, ordered after the producing kernels, so the exchange of bucket k
+overlaps the backward kernels of bucket k+1.  `finish()` makes the compute stream wait for all buckets and hands the
+averaged gradients back as views into the flat messages (no unflatten copy).
+
+Bucket = one transformer block (~12.6 M params = 50 MB fp32) -- large messages because a ring/tree over
+point-to-point xGMI links is per-link bandwidth bound, not latency bound; decoder_embed's 268 MB gradient is its own
+bucket so it is on the wire while the blocks are still being differentiated.
+
+Gradient accumulation: construct with `every=k` (or call `set_sync(False)`) to skip the exchange on non-update
+micro-steps -- the reference all-reduces on every micro-step because it never uses no_sync() (engine_train.py:85-90);
+the sum of micro-gradients is identical either way.
+"""
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, process_group=None, average=True):
+        self.group = process_group
+        self.average = average
+        self.enabled = True
+        self._pending = []
+
+    def set_sync(self, enabled: bool):
+        self.enabled = bool(enabled)
+
+    @property
+    def world_size(self):
+        return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+
+    def ready(self, G, names):
+        """Gradients `names` of dict G are enqueued: start their all-reduce, replace them by views of the flat message."""
+        if not self.enabled or self.world_size == 1:
+            return
+        ts = [G[n] for n in names]
+        flat = torch.cat([t.reshape(-1) for t in ts])                   # one contiguous fp32 message
+        backend = dist.get_backend(self.group)
+        if self.average and backend == "nccl":
+            work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+            post = None
+        else:
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            post = (1.0 / self.world_size) if self.average else None    # gloo (CPU tests) has no AVG
+        off = 0
+        for n, t in zip(names, ts):
+            G[n] = flat[off:off + t.numel()].view(t.shape)
+            off += t.numel()
+        self._pending.append((work, flat, post))
+
+    def finish(self):
+        for work, flat, post in self._pending:
+            work.wait()
+            if post is not None:
+                flat.mul_(post)
+        self._pending = []
+
+
+def init_distributed(backend=None):
+    """env:// rendezvous as torchrun sets it up (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT);
+    mirrors util/misc.py:217-249 without the SLURM/OMPI parsing."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 0, 1
+    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
+    return rank, local, world
