@@ -109,7 +109,7 @@ class KernelTimer:
 def cpu_baseline():
     """One fp32 forward+backward of the CPU oracle at B=1 (ViT-L, 896x448) on the host cores."""
     from oracle import painter_oracle as O
-    torch.set_num_threads(os.cpu_count())
+    torch.set_num_threads(min(os.cpu_count(), 32))     # more threads only add contention at B=1
     cfg = O.vit_large_config()
     P = {k: v.requires_grad_(True) for k, v in O.random_params(cfg, 1).items()}
     imgs, tgts, mask, valid = O.synthetic_batch(cfg, 1, 1234, "half")

@@ -26,7 +26,7 @@ def _digest(paths):
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
-            h.update(p.encode())
+            h.update(os.path.basename(p).encode())
             h.update(f.read())
     return h.hexdigest()
 

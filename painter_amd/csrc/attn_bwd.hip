@@ -34,9 +34,9 @@ extern "C" int pa_attn_bwd_delta(int dtype, const void* out, int64_t ldo, const 
                                  int heads, hipStream_t st) {
     const int R = batch * L;
     if (dtype == PA_BF16)
-        hipLaunchKernelGGL(attn_delta_kernel<bf16>, dim3((R + 3) / 4), dim3(256), 0, st, (const bf16*)out, (size_t)ldo, (const bf16*)dout, (size_t)lddo, delta, R, L, heads);
+        PA_LAUNCH(attn_delta_kernel<bf16>, dim3((R + 3) / 4), dim3(256), 0, st, (const bf16*)out, (size_t)ldo, (const bf16*)dout, (size_t)lddo, delta, R, L, heads);
     else
-        hipLaunchKernelGGL(attn_delta_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, st, (const float*)out, (size_t)ldo, (const float*)dout, (size_t)lddo, delta, R, L, heads);
+        PA_LAUNCH(attn_delta_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, st, (const float*)out, (size_t)ldo, (const float*)dout, (size_t)lddo, delta, R, L, heads);
     LAUNCH_CHECK();
 }
 
@@ -410,9 +410,9 @@ extern "C" int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* 
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
     const int n = NRP * ATT_HD;
     if (dtype == PA_BF16)
-        hipLaunchKernelGGL(relpos_pack_t_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (bf16*)rcatT, NRP);
+        PA_LAUNCH(relpos_pack_t_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (bf16*)rcatT, NRP);
     else
-        hipLaunchKernelGGL(relpos_pack_t_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (float*)rcatT, NRP);
+        PA_LAUNCH(relpos_pack_t_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (float*)rcatT, NRP);
     LAUNCH_CHECK();
 }
 
@@ -442,7 +442,7 @@ static int attn_bwd_t(const T* qkv, int64_t ldq, const T* rcat, const T* rcatT, 
             if (e != hipSuccess) return (int)e;
             done = true;
         }
-        hipLaunchKernelGGL(kern, dim3((qtiles + NW - 1) / NW, Bn * H), dim3(NW * 64), smem, st, qkv, (size_t)ldq, rcat, rcatT, dout,
+        PA_LAUNCH(kern, dim3((qtiles + NW - 1) / NW, Bn * H), dim3(NW * 64), smem, st, qkv, (size_t)ldq, rcat, rcatT, dout,
                            (size_t)lddo, lse, delta, dqkv, dG, aux, L, H, Hp, Wp, NRP, scale, ts);
         int e = (int)hipGetLastError();
         if (e) return e;
@@ -461,7 +461,7 @@ static int attn_bwd_t(const T* qkv, int64_t ldq, const T* rcat, const T* rcatT, 
             if (e != hipSuccess) return (int)e;
             done = true;
         }
-        hipLaunchKernelGGL(kern, dim3((qtiles + NW - 1) / NW, Bn * H), dim3(NW * 64), smem, st, qkv, (size_t)ldq, dout, (size_t)lddo,
+        PA_LAUNCH(kern, dim3((qtiles + NW - 1) / NW, Bn * H), dim3(NW * 64), smem, st, qkv, (size_t)ldq, dout, (size_t)lddo,
                            aux, dqkv, L, H, Hp, Wp, scale);
         return (int)hipGetLastError();
     }

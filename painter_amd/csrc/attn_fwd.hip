@@ -173,9 +173,9 @@ extern "C" int pa_relpos_pack(int dtype, const float* rel_pos_h, const float* re
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
     const int n = NRP * ATT_HD;
     if (dtype == PA_BF16)
-        hipLaunchKernelGGL(relpos_pack_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (bf16*)rcat, NRP);
+        PA_LAUNCH(relpos_pack_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (bf16*)rcat, NRP);
     else
-        hipLaunchKernelGGL(relpos_pack_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (float*)rcat, NRP);
+        PA_LAUNCH(relpos_pack_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (float*)rcat, NRP);
     LAUNCH_CHECK();
 }
 
@@ -200,7 +200,7 @@ static int attn_fwd_launch(const T* qkv, int64_t ldq, const T* rcat, T* out, int
     if (smem > 160 * 1024) return (int)hipErrorInvalidValue;
     const int qtiles = L / 32;
     dim3 grid((qtiles + NW - 1) / NW, Bn * H);
-    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, st, qkv, (size_t)ldq, rcat, out, (size_t)ldo, lse, L, H, Hp, Wp, NRP, scale, ts);
+    PA_LAUNCH(kern, grid, dim3(NW * 64), smem, st, qkv, (size_t)ldq, rcat, out, (size_t)ldo, lse, L, H, Hp, Wp, NRP, scale, ts);
     return (int)hipGetLastError();
 }
 

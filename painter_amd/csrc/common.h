@@ -125,4 +125,7 @@ DEVI uint4 cvt4(float a, float b, float c, float d, float*) {
 }
 DEVI uint2 cvt4(float a, float b, float c, float d, bf16*) { return make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d)); }
 
+// hipGetLastError() is sticky across unrelated runtime calls made by the host framework: clear it before launching so the
+// value returned after the launch belongs to this launch.
+#define PA_LAUNCH(...) do { (void)hipGetLastError(); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 #define LAUNCH_CHECK() return (int)hipGetLastError()

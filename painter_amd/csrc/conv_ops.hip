@@ -272,8 +272,8 @@ template <typename T> __global__ void conv3x3_pack_kernel(const float* w3, T* w3
 }
 extern "C" int pa_conv3x3_pack(int dtype, const float* w3, void* w3r, void* wf, hipStream_t st) {
     const int n = CV_C * CV_C * 9;
-    if (dtype == PA_BF16) hipLaunchKernelGGL(conv3x3_pack_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, w3, (bf16*)w3r, (bf16*)wf);
-    else hipLaunchKernelGGL(conv3x3_pack_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, w3, (float*)w3r, (float*)wf);
+    if (dtype == PA_BF16) PA_LAUNCH(conv3x3_pack_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, w3, (bf16*)w3r, (bf16*)wf);
+    else PA_LAUNCH(conv3x3_pack_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, w3, (float*)w3r, (float*)wf);
     LAUNCH_CHECK();
 }
 

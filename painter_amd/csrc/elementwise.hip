@@ -18,7 +18,7 @@ __global__ void cast_bf16_kernel(const float* __restrict__ in, bf16* __restrict_
 }
 extern "C" int pa_cast_bf16(const float* in, void* out, int64_t n, hipStream_t st) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(cast_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, in, (bf16*)out, (size_t)n);
+    PA_LAUNCH(cast_bf16_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, st, in, (bf16*)out, (size_t)n);
     LAUNCH_CHECK();
 }
 
@@ -47,11 +47,11 @@ __global__ void pos_bwd_kernel(const float* __restrict__ M, const float* __restr
 }
 // pe / dpe point at the first non-cls row of pos_embed ([S, D])
 extern "C" int pa_pos_fwd(const float* M, const float* pe, float* pos, int L, int S, int D, hipStream_t st) {
-    hipLaunchKernelGGL(pos_fwd_kernel, dim3((D + 255) / 256, L), dim3(256), 0, st, M, pe, pos, L, S, D);
+    PA_LAUNCH(pos_fwd_kernel, dim3((D + 255) / 256, L), dim3(256), 0, st, M, pe, pos, L, S, D);
     LAUNCH_CHECK();
 }
 extern "C" int pa_pos_bwd(const float* M, const float* gx, const float* gy, float* dpe, int L, int S, int D, hipStream_t st) {
-    hipLaunchKernelGGL(pos_bwd_kernel, dim3((D + 255) / 256, S), dim3(256), 0, st, M, gx, gy, dpe, L, S, D);
+    PA_LAUNCH(pos_bwd_kernel, dim3((D + 255) / 256, S), dim3(256), 0, st, M, gx, gy, dpe, L, S, D);
     LAUNCH_CHECK();
 }
 
@@ -83,8 +83,8 @@ extern "C" int pa_tokens_bwd(int dtype, const float* dx0, const unsigned char* m
                              int batch, int L, int D, hipStream_t st) {
     if (D % 4) return (int)hipErrorInvalidValue;
     dim3 grid((D / 4 + 63) / 64, L);
-    if (dtype == PA_BF16) hipLaunchKernelGGL(tokens_bwd_kernel<bf16>, grid, dim3(64), 0, st, dx0, mask, mask_batch_stride, (bf16*)dpe, sums, batch, L, D);
-    else hipLaunchKernelGGL(tokens_bwd_kernel<float>, grid, dim3(64), 0, st, dx0, mask, mask_batch_stride, (float*)dpe, sums, batch, L, D);
+    if (dtype == PA_BF16) PA_LAUNCH(tokens_bwd_kernel<bf16>, grid, dim3(64), 0, st, dx0, mask, mask_batch_stride, (bf16*)dpe, sums, batch, L, D);
+    else PA_LAUNCH(tokens_bwd_kernel<float>, grid, dim3(64), 0, st, dx0, mask, mask_batch_stride, (float*)dpe, sums, batch, L, D);
     LAUNCH_CHECK();
 }
 
@@ -97,7 +97,7 @@ __global__ void merge_fwd_kernel(const float* __restrict__ x, float* __restrict_
 }
 extern "C" int pa_merge_fwd(const float* x, float* out, int64_t n_out, hipStream_t st) {
     if (n_out % 4) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(merge_fwd_kernel, dim3((unsigned)((n_out / 4 + 255) / 256)), dim3(256), 0, st, x, out, (size_t)n_out);
+    PA_LAUNCH(merge_fwd_kernel, dim3((unsigned)((n_out / 4 + 255) / 256)), dim3(256), 0, st, x, out, (size_t)n_out);
     LAUNCH_CHECK();
 }
 // dx[both halves] = 0.5 * dmerged; dxT = rowscale[row / rps] * dx (T copy for the next GEMM operand)
@@ -121,8 +121,8 @@ extern "C" int pa_merge_bwd(int dtype, const float* dmerged, float* dx, void* dx
     if (D % 4) return (int)hipErrorInvalidValue;
     const size_t n = (size_t)rows_half * D;
     dim3 grid((unsigned)((n / 4 + 255) / 256));
-    if (dtype == PA_BF16) hipLaunchKernelGGL(merge_bwd_kernel<bf16>, grid, dim3(256), 0, st, dmerged, dx, (bf16*)dxT, rowscale, rows_per_sample, (size_t)rows_half, D);
-    else hipLaunchKernelGGL(merge_bwd_kernel<float>, grid, dim3(256), 0, st, dmerged, dx, (float*)dxT, rowscale, rows_per_sample, (size_t)rows_half, D);
+    if (dtype == PA_BF16) PA_LAUNCH(merge_bwd_kernel<bf16>, grid, dim3(256), 0, st, dmerged, dx, (bf16*)dxT, rowscale, rows_per_sample, (size_t)rows_half, D);
+    else PA_LAUNCH(merge_bwd_kernel<float>, grid, dim3(256), 0, st, dmerged, dx, (float*)dxT, rowscale, rows_per_sample, (size_t)rows_half, D);
     LAUNCH_CHECK();
 }
 // scaled T copy of an fp32 matrix: out = rowscale[row / rps] * in
@@ -139,8 +139,8 @@ extern "C" int pa_scale_cast(int dtype, const float* in, void* out, const float*
     if (D % 4) return (int)hipErrorInvalidValue;
     const size_t n = (size_t)rows * D;
     dim3 grid((unsigned)((n / 4 + 255) / 256));
-    if (dtype == PA_BF16) hipLaunchKernelGGL(scale_cast_kernel<bf16>, grid, dim3(256), 0, st, in, (bf16*)out, rowscale, rows_per_sample, n, D);
-    else hipLaunchKernelGGL(scale_cast_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, rowscale, rows_per_sample, n, D);
+    if (dtype == PA_BF16) PA_LAUNCH(scale_cast_kernel<bf16>, grid, dim3(256), 0, st, in, (bf16*)out, rowscale, rows_per_sample, n, D);
+    else PA_LAUNCH(scale_cast_kernel<float>, grid, dim3(256), 0, st, in, (float*)out, rowscale, rows_per_sample, n, D);
     LAUNCH_CHECK();
 }
 
@@ -171,7 +171,7 @@ __global__ void ensemble_resid_kernel(const float* __restrict__ x0, const float*
 }
 extern "C" int pa_ensemble_resid(const float* x0, const float* a, float* x1, int batch, int group, int L, int D, hipStream_t st) {
     if (D % 4 || group <= 0 || batch % group) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(ensemble_resid_kernel, dim3((D / 4 + 63) / 64, L), dim3(64), 0, st, x0, a, x1, batch, group, L, D);
+    PA_LAUNCH(ensemble_resid_kernel, dim3((D / 4 + 63) / 64, L), dim3(64), 0, st, x0, a, x1, batch, group, L, D);
     LAUNCH_CHECK();
 }
 
@@ -281,12 +281,12 @@ extern "C" int pa_loss_fwd(const float* pred, const float* tgts, float* valid, c
     float* ipart = part + (size_t)batch * nblk * 2;                    // [batch][nblk]
     float* flag = ipart + (size_t)batch * nblk;                        // [batch]
     if (ignore_rule) {
-        hipLaunchKernelGGL(loss_ignore_part_kernel, dim3(nblk, batch), dim3(LOSS_BLK), 0, st, tgts, mask, mask_batch_stride, ipart, HW, Wi, P, Wp);
-        hipLaunchKernelGGL(loss_ignore_flag_kernel, dim3(batch), dim3(LOSS_BLK), 0, st, ipart, nblk, flag, 300.f);
+        PA_LAUNCH(loss_ignore_part_kernel, dim3(nblk, batch), dim3(LOSS_BLK), 0, st, tgts, mask, mask_batch_stride, ipart, HW, Wi, P, Wp);
+        PA_LAUNCH(loss_ignore_flag_kernel, dim3(batch), dim3(LOSS_BLK), 0, st, ipart, nblk, flag, 300.f);
     }
-    hipLaunchKernelGGL(loss_part_kernel, dim3(nblk, batch), dim3(LOSS_BLK), 0, st, pred, tgts, valid, mask, mask_batch_stride,
+    PA_LAUNCH(loss_part_kernel, dim3(nblk, batch), dim3(LOSS_BLK), 0, st, pred, tgts, valid, mask, mask_batch_stride,
                        ignore_rule ? flag : (const float*)nullptr, part, HW, Wi, P, Wp, kind, beta);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(LOSS_BLK), 0, st, part, batch * nblk, eps_den, out);
+    PA_LAUNCH(loss_final_kernel, dim3(1), dim3(LOSS_BLK), 0, st, part, batch * nblk, eps_den, out);
     LAUNCH_CHECK();
 }
 __global__ void loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ tgts, const float* __restrict__ valid,
@@ -303,7 +303,7 @@ extern "C" int pa_loss_bwd(const float* pred, const float* tgts, const float* va
                            const float* dloss, const float* loss_out, float* dpred, int batch, int Hi, int Wi, int P, int kind,
                            float beta, hipStream_t st) {
     const int HW = Hi * Wi;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3((3 * HW + 255) / 256, batch), dim3(256), 0, st, pred, tgts, valid, mask, mask_batch_stride,
+    PA_LAUNCH(loss_bwd_kernel, dim3((3 * HW + 255) / 256, batch), dim3(256), 0, st, pred, tgts, valid, mask, mask_batch_stride,
                        dloss, loss_out, dpred, HW, Wi, P, Wi / P, kind, beta);
     LAUNCH_CHECK();
 }
@@ -321,7 +321,7 @@ __global__ void patchify_kernel(const float* __restrict__ img, float* __restrict
 }
 extern "C" int pa_patchify(const float* img, float* out, int batch, int Hp, int Wp, int P, hipStream_t st) {
     const size_t n = (size_t)batch * Hp * Wp * P * P * 3;
-    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, img, out, Hp, Wp, P, n);
+    PA_LAUNCH(patchify_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, img, out, Hp, Wp, P, n);
     LAUNCH_CHECK();
 }
 
@@ -414,9 +414,9 @@ extern "C" int pa_decoder_tail_bwd_pointwise(int dtype, const float* dpred, cons
     const int npix = batch * Hi * Wi, nb = tail_bwd_blocks(npix);
     float* part = reinterpret_cast<float*>(workspace);
     if (dtype == PA_BF16)
-        hipLaunchKernelGGL(tail_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, dpred, (const bf16*)y3, ln_gamma, ln_beta, w1, (bf16*)dy3, part, Hi * Wi, npix, eps);
+        PA_LAUNCH(tail_bwd_kernel<bf16>, dim3(nb), dim3(256), 0, st, dpred, (const bf16*)y3, ln_gamma, ln_beta, w1, (bf16*)dy3, part, Hi * Wi, npix, eps);
     else
-        hipLaunchKernelGGL(tail_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, dpred, (const float*)y3, ln_gamma, ln_beta, w1, (float*)dy3, part, Hi * Wi, npix, eps);
+        PA_LAUNCH(tail_bwd_kernel<float>, dim3(nb), dim3(256), 0, st, dpred, (const float*)y3, ln_gamma, ln_beta, w1, (float*)dy3, part, Hi * Wi, npix, eps);
     int e = (int)hipGetLastError();
     if (e) return e;
     return pa_slab_reduce(part, grads, TAILP, nb, TAILP, 0, st);

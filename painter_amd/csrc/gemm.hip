@@ -69,29 +69,49 @@ struct EpiSlab {   // fp32 partial result of split z (wgrad)
 };
 
 // ------------------------------------------------------------------------------- reductions
-// out[n] = (accumulate ? out[n] : 0) + sum_z in[z * stride + n]
-__global__ void slab_reduce_kernel(const float* in, float* out, size_t n, int nz, size_t stride, int accumulate) {
-    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    if (i + 4 <= n) {
-        float4 s = accumulate ? *reinterpret_cast<const float4*>(out + i) : make_float4(0, 0, 0, 0);
-        for (int z = 0; z < nz; ++z) {
+// out[n] = (accumulate ? out[n] : 0) + sum_z in[z * stride + n]      (n % 4 == 0)
+// block = 16 column-groups (float4) x 16 z-lanes; the z loop is strided over the z-lanes and unrolled so that many loads
+// are in flight, then the 16 partial sums are combined through LDS in a fixed order (deterministic).
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ in, float* out, size_t n, int nz, size_t stride, int accumulate) {
+    __shared__ float4 sh[16][17];
+    const int cg = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const size_t i = ((size_t)blockIdx.x * 16 + cg) * 4;
+    float4 s = make_float4(0, 0, 0, 0);
+    if (i < n) {
+#pragma unroll 4
+        for (int z = zl; z < nz; z += 16) {
             const float4 v = *reinterpret_cast<const float4*>(in + (size_t)z * stride + i);
             s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
         }
-        *reinterpret_cast<float4*>(out + i) = s;
-    } else {
-        for (; i < n; ++i) {
-            float s = accumulate ? out[i] : 0.f;
-            for (int z = 0; z < nz; ++z) s += in[(size_t)z * stride + i];
-            out[i] = s;
-        }
     }
+    sh[zl][cg] = s;
+    __syncthreads();
+    if (zl == 0 && i < n) {
+        float4 t = accumulate ? *reinterpret_cast<const float4*>(out + i) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const float4 v = sh[k][cg]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(out + i) = t;
+    }
+}
+// few slabs, large n: one float4 per thread, plain loop
+__global__ void slab_reduce_wide_kernel(const float* __restrict__ in, float* out, size_t n, int nz, size_t stride, int accumulate) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= n) return;
+    float4 s = accumulate ? *reinterpret_cast<const float4*>(out + i) : make_float4(0, 0, 0, 0);
+#pragma unroll 4
+    for (int z = 0; z < nz; ++z) {
+        const float4 v = *reinterpret_cast<const float4*>(in + (size_t)z * stride + i);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i) = s;
 }
 extern "C" int pa_slab_reduce(const float* in, float* out, int64_t n, int nz, int64_t stride, int accumulate, hipStream_t st) {
     if (n <= 0) return 0;
-    const int blocks = (int)((n + 1023) / 1024);
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, st, in, out, (size_t)n, nz, (size_t)stride, accumulate);
+    if (n % 4 || stride % 4) return (int)hipErrorInvalidValue;
+    if (nz <= 16 && n >= (1 << 18))
+        PA_LAUNCH(slab_reduce_wide_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, in, out, (size_t)n, nz, (size_t)stride, accumulate);
+    else
+        PA_LAUNCH(slab_reduce_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, in, out, (size_t)n, nz, (size_t)stride, accumulate);
     LAUNCH_CHECK();
 }
 
@@ -129,9 +149,9 @@ extern "C" int pa_colsum(int dtype, const void* x, int64_t ld, int M, int N, flo
     float* part = reinterpret_cast<float*>(workspace);
     dim3 grid((N / 4 + 63) / 64, chunks);
     if (dtype == PA_BF16)
-        hipLaunchKernelGGL(colsum_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (size_t)ld, M, N, rpc, part);
+        PA_LAUNCH(colsum_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (size_t)ld, M, N, rpc, part);
     else
-        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (size_t)ld, M, N, rpc, part);
+        PA_LAUNCH(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (size_t)ld, M, N, rpc, part);
     int e = (int)hipGetLastError();
     if (e) return e;
     return pa_slab_reduce(part, out, N, chunks, N, 0, st);

@@ -237,7 +237,7 @@ static int launch_gemm(AOp A, BOp B, Epi epi, int M, int N, int K, int nsplit, i
         attr_done = true;
     }
     if (tiles <= 0 || M <= 0 || N <= 0) return 0;
-    hipLaunchKernelGGL(kern, dim3(tiles, 1, nsplit * nbatch), dim3(WM * WN * 64), smem, st, A, B, epi, M, N, K,
+    PA_LAUNCH(kern, dim3(tiles, 1, nsplit * nbatch), dim3(WM * WN * 64), smem, st, A, B, epi, M, N, K,
                        klen, nbatch);
     return (int)hipGetLastError();
 }

@@ -139,7 +139,7 @@ static int ln_fwd_t(const float* x, int64_t ldx, const float* g, const float* b,
                     float* rstd, int R, int D, hipStream_t st) {
     const int ni = (D + 255) / 256;
     dim3 grid((R + 3) / 4), blk(256);
-#define LN_FWD(NI) hipLaunchKernelGGL((ln_fwd_kernel<T, NI>), grid, blk, 0, st, x, (size_t)ldx, g, b, eps, y, (size_t)ldy, mean, rstd, R, D)
+#define LN_FWD(NI) PA_LAUNCH((ln_fwd_kernel<T, NI>), grid, blk, 0, st, x, (size_t)ldx, g, b, eps, y, (size_t)ldy, mean, rstd, R, D)
     if (ni <= 1) LN_FWD(1);
     else if (ni <= 2) LN_FWD(2);
     else if (ni <= 4) LN_FWD(4);
@@ -170,7 +170,7 @@ static int ln_bwd_t(const T* dy, int64_t lddy, const float* x, int64_t ldx, cons
     const int nb = ln_bwd_blocks(R);
     dim3 grid(nb), blk(256);
     const size_t sm = (size_t)8 * D * sizeof(float);
-#define LN_BWD(NI) hipLaunchKernelGGL((ln_bwd_kernel<T, NI>), grid, blk, sm, st, dy, (size_t)lddy, x, (size_t)ldx, mean, rstd, gamma, dres, dx, (size_t)lddx, dxT, (size_t)lddxT, rowscale, rps, ws, R, D)
+#define LN_BWD(NI) PA_LAUNCH((ln_bwd_kernel<T, NI>), grid, blk, sm, st, dy, (size_t)lddy, x, (size_t)ldx, mean, rstd, gamma, dres, dx, (size_t)lddx, dxT, (size_t)lddxT, rowscale, rps, ws, R, D)
     if (ni <= 1) LN_BWD(1);
     else if (ni <= 2) LN_BWD(2);
     else if (ni <= 4) LN_BWD(4);
