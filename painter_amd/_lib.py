@@ -47,6 +47,9 @@ class _Lib:
                 raise RuntimeError(
                     "painter_amd: %s is missing -- run `python -m painter_amd.build` (or __graft_entry__.build()). "
                     "There is no CPU / PyTorch fallback for the hot path." % LIB_PATH)
+            # torch bundles its own libamdhip64: it has to be in the process before ours resolves the HIP runtime, otherwise
+            # two runtimes end up loaded and launches on torch's streams fail with hipErrorNoDevice.
+            import torch  # noqa: F401
             dll = ctypes.CDLL(LIB_PATH)
             for name, (ret, args) in self._protos.items():
                 fn = getattr(dll, name)          # AttributeError here = header/library drift: fail loudly

@@ -2,6 +2,7 @@
 // Replaces the reference's ATen addmm/mm calls at Painter/models_painter.py:76 (qkv), :87 (proj),
 // timm Mlp fc1/fc2 (:201,:230), :423 (decoder_embed) and their autograd backward (SURVEY.md 8a a4,a9,a10,a13,a17).
 #include "gemm_engine.h"
+#include "gemm256.h"
 #include "../../include/painter_hip.h"
 
 // ------------------------------------------------------------------------------- epilogues
@@ -65,6 +66,69 @@ struct EpiSlab {   // fp32 partial result of split z (wgrad)
         foreach_acc(acc, ib, jb, lane, [&](int i, int j, float v) {
             if (i < M && j < N) o[(size_t)i * ldo + j] = v;
         });
+    }
+};
+
+// ---- 4-wide epilogues of the 256x256 bf16 kernel (gemm256.h): (row i, column j % 4 == 0, D[i][j..j+3], split)
+DEVI void store4(bf16* p, float4 v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
+DEVI void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+DEVI float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+DEVI float4 load4(const bf16* p) {
+    const uint2 w = *reinterpret_cast<const uint2*>(p);
+    return make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+}
+template <typename OutT> struct Epi4Bias {
+    OutT* out; size_t ldo; const float* bias; int M, N;
+    DEVI void operator()(int i, int j, float4 v, int) const {
+        if (i >= M || j >= N) return;
+        if (bias) { const float4 b = load4(bias + j); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        store4(out + (size_t)i * ldo + j, v);
+    }
+};
+struct Epi4BiasGelu {
+    bf16* pre; bf16* act; size_t ld; const float* bias; int M, N;
+    DEVI void operator()(int i, int j, float4 v, int) const {
+        if (i >= M || j >= N) return;
+        const float4 b = load4(bias + j);
+        const uint2 pk = make_uint2(pack_bf16x2(v.x + b.x, v.y + b.y), pack_bf16x2(v.z + b.z, v.w + b.w));
+        if (pre) *reinterpret_cast<uint2*>(pre + (size_t)i * ld + j) = pk;
+        store4(act + (size_t)i * ld + j, make_float4(gelu_f(bf16_lo(pk.x)), gelu_f(bf16_hi(pk.x)), gelu_f(bf16_lo(pk.y)), gelu_f(bf16_hi(pk.y))));
+    }
+};
+struct Epi4BiasResid {
+    float* out; const float* resid; size_t ld; const float* bias; const float* rowscale; int rps; int M, N;
+    DEVI void operator()(int i, int j, float4 v, int) const {
+        if (i >= M || j >= N) return;
+        const float s = rowscale ? rowscale[i / rps] : 1.f;
+        const float4 b = load4(bias + j), r = load4(resid + (size_t)i * ld + j);
+        store4(out + (size_t)i * ld + j, make_float4(r.x + s * (v.x + b.x), r.y + s * (v.y + b.y), r.z + s * (v.z + b.z), r.w + s * (v.w + b.w)));
+    }
+};
+struct Epi4DGelu {
+    bf16* out; const bf16* pre; size_t ld; int M, N;
+    DEVI void operator()(int i, int j, float4 v, int) const {
+        if (i >= M || j >= N) return;
+        const float4 p = load4(pre + (size_t)i * ld + j);
+        store4(out + (size_t)i * ld + j, make_float4(v.x * gelu_grad_f(p.x), v.y * gelu_grad_f(p.y), v.z * gelu_grad_f(p.z), v.w * gelu_grad_f(p.w)));
+    }
+};
+struct Epi4PixShuf {
+    bf16* out; const float* bias; int Hp, Wp, P, C, M, N;
+    DEVI void operator()(int i, int j, float4 v, int) const {
+        if (i >= M || j >= N) return;
+        const int L = Hp * Wp;
+        const int b = i / L, l = i - b * L, h = l / Wp, w = l - h * Wp;
+        const int c = j % C, pq = j / C, q = pq % P, p = pq / P;
+        const size_t y = (size_t)b * Hp * P + h * P + p, x = (size_t)w * P + q;
+        const float4 bb = load4(bias + j);
+        store4(out + (y * (size_t)(Wp * P) + x) * C + c, make_float4(v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w));
+    }
+};
+struct Epi4Slab {
+    float* out; size_t ldo; size_t slab; int M, N;
+    DEVI void operator()(int i, int j, float4 v, int split) const {
+        if (i >= M || j >= N) return;
+        store4(out + (size_t)split * slab + (size_t)i * ldo + j, v);
     }
 };
 
@@ -162,6 +226,20 @@ template <typename T>
 static int linear_fwd_t(int epi, const T* x, int64_t ldx, const T* w, const float* bias, void* out, void* out2,
                         int64_t ldo, const float* resid, const float* rowscale, int rps, int M, int N, int K,
                         hipStream_t st) {
+    if constexpr (std::is_same<T, bf16>::value) {
+        if (g256::ok(M, N, K, false, false, ldx, K) && N % 4 == 0) {
+            switch (epi) {
+            case PA_EPI_BIAS:
+                return g256::launch<false, false>(x, ldx, w, K, Epi4Bias<bf16>{(bf16*)out, (size_t)ldo, bias, M, N}, M, N, K, 1, st);
+            case PA_EPI_BIAS_F32:
+                return g256::launch<false, false>(x, ldx, w, K, Epi4Bias<float>{(float*)out, (size_t)ldo, bias, M, N}, M, N, K, 1, st);
+            case PA_EPI_BIAS_GELU:
+                return g256::launch<false, false>(x, ldx, w, K, Epi4BiasGelu{(bf16*)out2, (bf16*)out, (size_t)ldo, bias, M, N}, M, N, K, 1, st);
+            case PA_EPI_BIAS_RESID:
+                return g256::launch<false, false>(x, ldx, w, K, Epi4BiasResid{(float*)out, resid, (size_t)ldo, bias, rowscale, rps, M, N}, M, N, K, 1, st);
+            }
+        }
+    }
     OpN<T> A{x, (size_t)ldx, M, 0};
     OpN<T> B{w, (size_t)K, N, 0};
     switch (epi) {
@@ -190,6 +268,10 @@ template <typename T>
 static int linear_pixshuf_t(const T* x, int64_t ldx, const T* w, const float* bias, T* out, int Bn, int Hp, int Wp,
                             int P, int C, int K, hipStream_t st) {
     const int M = Bn * Hp * Wp, N = P * P * C;
+    if constexpr (std::is_same<T, bf16>::value) {
+        if (g256::ok(M, N, K, false, false, ldx, K) && C % 4 == 0)
+            return g256::launch<false, false>(x, ldx, w, K, Epi4PixShuf{out, bias, Hp, Wp, P, C, M, N}, M, N, K, 1, st);
+    }
     OpN<T> A{x, (size_t)ldx, M, 0};
     OpN<T> B{w, (size_t)K, N, 0};
     return launch_gemm<T, 2, 2>(A, B, EpiPixShuf<T>{out, bias, Hp, Wp, P, C, M, N}, M, N, K, 1, 1, st);
@@ -206,6 +288,12 @@ extern "C" int pa_linear_pixshuf(int dtype, const void* x, int64_t ldx, const vo
 template <typename T>
 static int linear_dgrad_t(const T* dy, int64_t lddy, const T* w, const T* pre, T* dx, int64_t lddx, int M, int N, int K,
                           hipStream_t st) {
+    if constexpr (std::is_same<T, bf16>::value) {
+        if (g256::ok(M, K, N, false, true, lddy, K) && K % 4 == 0) {
+            if (pre) return g256::launch<false, true>(dy, lddy, w, K, Epi4DGelu{dx, pre, (size_t)lddx, M, K}, M, K, N, 1, st);
+            return g256::launch<false, true>(dy, lddy, w, K, Epi4Bias<bf16>{dx, (size_t)lddx, nullptr, M, K}, M, K, N, 1, st);
+        }
+    }
     OpN<T> A{dy, (size_t)lddy, M, 0};
     OpT<T> B{w, (size_t)K, K, 0};
     if (pre) return launch_gemm<T, 2, 2>(A, B, EpiDGelu<T>{dx, pre, (size_t)lddx, M, K}, M, K, N, 1, 1, st);
@@ -219,6 +307,17 @@ extern "C" int pa_linear_dgrad(int dtype, const void* dy, int64_t lddy, const vo
 }
 
 // dW[N,K] = dY[M,N]^T . X[M,K]    (contraction over M; both operands contraction-major), split-K + reduce
+static bool wgrad_fast(int dtype, int M, int N, int K) {
+    return dtype == PA_BF16 && g256::ok(N, K, M, true, true, N, K) && K % 4 == 0 && N % 256 == 0 && K % 256 == 0;
+}
+static int wgrad_fast_splits(int M, int N, int K) {
+    const int tiles = (N / 256) * (K / 256);
+    int s = (256 + tiles / 2) / tiles;
+    if (s < 1) s = 1;
+    const int ktiles = M / 64;
+    if (s > ktiles / 4) s = ktiles / 4 > 0 ? ktiles / 4 : 1;
+    return g256::splits_used(M, s);
+}
 static int wgrad_splits(int M, int N, int K, int bk) {
     const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
     const int nku = (M + bk - 1) / bk;
@@ -229,12 +328,25 @@ static int wgrad_splits(int M, int N, int K, int bk) {
     return s;
 }
 extern "C" int64_t pa_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K) {
+    if (wgrad_fast(dtype, M, N, K)) {
+        const int s = wgrad_fast_splits(M, N, K);
+        return s > 1 ? (int64_t)s * N * K * sizeof(float) : 0;
+    }
     const int s = wgrad_splits(M, N, K, dtype == PA_BF16 ? 64 : 32);
     return s > 1 ? (int64_t)s * N * K * sizeof(float) : 0;
 }
 template <typename T>
 static int linear_wgrad_t(const T* dy, int64_t lddy, const T* x, int64_t ldx, float* dw, float* ws, int M, int N, int K,
                           hipStream_t st) {
+    if constexpr (std::is_same<T, bf16>::value) {
+        if (wgrad_fast(PA_BF16, M, N, K) && g256::ok(N, K, M, true, true, lddy, ldx)) {
+            const int s = wgrad_fast_splits(M, N, K);
+            if (s == 1) return g256::launch<true, true>(dy, lddy, x, ldx, Epi4Slab{dw, (size_t)K, 0, N, K}, N, K, M, 1, st);
+            int e = g256::launch<true, true>(dy, lddy, x, ldx, Epi4Slab{ws, (size_t)K, (size_t)N * K, N, K}, N, K, M, s, st);
+            if (e) return e;
+            return pa_slab_reduce(ws, dw, (int64_t)N * K, s, (int64_t)N * K, 0, st);
+        }
+    }
     OpT<T> A{dy, (size_t)lddy, N, 0};
     OpT<T> B{x, (size_t)ldx, K, 0};
     const int s = wgrad_splits(M, N, K, TT<T>::BK);

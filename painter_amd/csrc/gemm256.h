@@ -1,0 +1,327 @@
+// bf16 MFMA GEMM for the big nn.Linear contractions of the ViT blocks:
+//     D[i][j] = sum_k A(i,k) * B(j,k),   fp32 accumulate
+// 256 x 256 output tile per workgroup of 8 waves (2 along i x 4 along j, 128 x 64 per wave, 32x32x16 MFMA), contraction
+// tiles of 64, operands staged HBM -> LDS by LDS-DMA (global_load_lds_dwordx4), never through VGPRs.
+//
+// Each operand may be stored contraction-contiguous ("K-major": X and W of y = x.W^T) or row-contiguous ("M-major":
+// W in dX = dY.W, both dY and X in dW = dY^T.X).  K-major tiles are read back as ds_read_b128 fragments from an
+// XOR-swizzled [row][64 k] image; M-major tiles keep the memory order ([k][row]) in LDS and are read with the gfx950
+// transposing read ds_read_b64_tr_b16, so no transposed copy of an activation or a weight ever exists in HBM.
+//
+// Schedule (per contraction tile: 4 phases = the 4 quadrants of the wave's 128 x 64 tile):
+//     phase = { ds_read this quadrant's new fragments | issue one 16 KB staging unit (2 LDS-DMA per lane) |
+//               s_waitcnt vmcnt(8) } barrier { 8 MFMA } barrier
+// The two wave rows run half a phase apart (the lower row takes one extra barrier on entry), so on every SIMD one wave
+// feeds the matrix pipe while its partner issues LDS reads and DMA.  LDS holds 8 staging units (2 stages x {a0,a1,b0,b1},
+// a unit = the rows every wave needs in the same phase); a unit is re-staged two phases after its last read and read five
+// phases after its DMA was issued, so HBM/L2 latency is covered by ~2.5k cycles of MFMA work and vmcnt never drains to 0
+// inside the loop.  Hazard rules followed (MI355X guide, 8-phase template): a DMA is waited for (counted vmcnt) before
+// the first barrier of phase p and read in phase p+1 or later; a unit is re-staged >= 2 phases after its last ds_read.
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+namespace g256 {
+
+constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
+constexpr int LDS_BYTES = 131072;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+// LDS map: A units at [0, 64K): a_sub * 32K + stage * 16K; B units at [64K, 128K) likewise.  Keeps every ds_read
+// immediate offset below 64K relative to one per-lane base register per operand.
+DEVI constexpr int unit_off(bool isB, int sub, int stage) { return (isB ? 65536 : 0) + sub * 32768 + stage * 16384; }
+
+template <int N> DEVI void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+DEVI void wait_lgkm0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// source byte offset (from the operand's tile-0 base) of the 16-byte chunk that lane `tid` moves with DMA `j` of a unit
+template <bool MM, bool IS_A>
+DEVI uint32_t src_off(int tid, int j, int sub, int tile0, int rows, uint32_t ld) {
+    const int cidx = j * NT + tid;
+    if constexpr (!MM) {
+        const int u = cidx >> 3, p = cidx & 7;
+        const int kc = p ^ ((u >> 1) & 7);
+        int row = IS_A ? ((u >> 6) * 128 + sub * 64 + (u & 63)) : ((u >> 5) * 64 + sub * 32 + (u & 31));
+        row = min(tile0 + row, rows - 1);
+        return ((uint32_t)row * ld + kc * 8) * 2u;
+    } else {
+        const int k = cidx >> 4, cp = cidx & 15;
+        const int c = cp ^ (4 * (k & 3));
+        int n = IS_A ? ((c >> 3) * 128 + sub * 64 + (c & 7) * 8) : ((c >> 2) * 64 + sub * 32 + (c & 3) * 8);
+        n = min(tile0 + n, rows - 8);
+        return ((uint32_t)k * ld + n) * 2u;
+    }
+}
+
+// keeps a wave-uniform pointer in SGPRs so that the DMA uses the (sgpr base + 32-bit vgpr offset) addressing form
+DEVI const unsigned char* sgpr_ptr(const unsigned char* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+DEVI void dma16(const unsigned char* g, unsigned char* l) {
+    __builtin_amdgcn_global_load_lds((gbl_cvoid*)g, (lds_void*)l, 16, 0, 0);
+}
+
+// fragment reads are inline asm on purpose: a compiler-visible LDS load makes hipcc wait vmcnt(0) for every LDS-DMA in
+// flight (it cannot prove the DMA does not alias), which would serialise the pipeline.
+template <int OFF> DEVI void lds_read128(uint4& d, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF> DEVI void lds_read64_tr(uint2& d, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+
+// one operand sub-tile of 32 rows x 64 k held by a wave: 4 k-steps of 8 contraction values per lane.  K-major: one
+// ds_read_b128 per k-step; M-major: two transposing 64-bit reads (k 0-3 | k 4-7 of the lane's 8) per k-step.
+template <bool MM> struct Frag4;
+template <> struct Frag4<false> {
+    uint4 q0, q1, q2, q3;
+    template <int IMM> DEVI void read(const uint32_t (&base)[4], int) {
+        lds_read128<IMM>(q0, base[0]);
+        lds_read128<IMM>(q1, base[1]);
+        lds_read128<IMM>(q2, base[2]);
+        lds_read128<IMM>(q3, base[3]);
+    }
+    template <int KS> DEVI bf16x8 k() const {
+        return __builtin_bit_cast(bf16x8, KS == 0 ? q0 : KS == 1 ? q1 : KS == 2 ? q2 : q3);
+    }
+};
+template <> struct Frag4<true> {
+    uint2 l0, h0, l1, h1, l2, h2, l3, h3;
+    template <int IMM> DEVI void read(const uint32_t (&base)[4], int which_mb) {
+        const uint32_t b = base[which_mb];
+        lds_read64_tr<IMM + 0 * 4096>(l0, b);
+        lds_read64_tr<IMM + 0 * 4096 + 1024>(h0, b);
+        lds_read64_tr<IMM + 1 * 4096>(l1, b);
+        lds_read64_tr<IMM + 1 * 4096 + 1024>(h1, b);
+        lds_read64_tr<IMM + 2 * 4096>(l2, b);
+        lds_read64_tr<IMM + 2 * 4096 + 1024>(h2, b);
+        lds_read64_tr<IMM + 3 * 4096>(l3, b);
+        lds_read64_tr<IMM + 3 * 4096 + 1024>(h3, b);
+    }
+    template <int KS> DEVI bf16x8 k() const {
+        typedef __attribute__((ext_vector_type(2))) uint32_t u2;
+        typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+        const uint2 l = KS == 0 ? l0 : KS == 1 ? l1 : KS == 2 ? l2 : l3;
+        const uint2 h = KS == 0 ? h0 : KS == 1 ? h1 : KS == 2 ? h2 : h3;
+        u2 lv = {l.x, l.y}, hv = {h.x, h.y};
+        return __builtin_bit_cast(bf16x8, __builtin_shufflevector(lv, hv, 0, 1, 2, 3));
+    }
+};
+
+// Epilogue contract: epi(i, j, v) with j a multiple of 4 and v = D[i][j..j+3]; the functor bounds-checks.
+template <bool AMM, bool BMM, class Epi>
+__global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag, uint32_t lda, const bf16* __restrict__ Bg,
+                                                      uint32_t ldb, Epi epi, int M, int N, int ktiles, int ktiles_per_split,
+                                                      int tiles_n) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wv >> 2, wc = wv & 3;
+
+    // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles (j fastest) so that the
+    // tiles sharing an A row panel hit the same L2.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int i0 = tm * BM, j0 = tn * BN;
+    const int split = blockIdx.y;
+    const int kt0 = split * ktiles_per_split;
+    const int nt = min(ktiles - kt0, ktiles_per_split);
+
+    // ---- DMA sources: 8 per lane (4 units x 2), as byte offsets from a wave-uniform, per-tile advancing base
+    uint32_t oa[2][2], ob[2][2];
+#pragma unroll
+    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            oa[sub][j] = src_off<AMM, true>(tid, j, sub, i0, M, lda);
+            ob[sub][j] = src_off<BMM, false>(tid, j, sub, j0, N, ldb);
+        }
+    const size_t a_step = AMM ? (size_t)BK * lda * 2 : (size_t)BK * 2;
+    const size_t b_step = BMM ? (size_t)BK * ldb * 2 : (size_t)BK * 2;
+    const unsigned char* abase = reinterpret_cast<const unsigned char*>(Ag) + (size_t)kt0 * a_step;
+    const unsigned char* bbase = reinterpret_cast<const unsigned char*>(Bg) + (size_t)kt0 * b_step;
+    unsigned char* const dma_dst = smem + wv * 1024;
+
+    auto stage_a = [&](int sub, int stage, int kt) {
+        const unsigned char* s = sgpr_ptr(abase + (size_t)kt * a_step);
+        dma16(s + oa[sub][0], dma_dst + unit_off(false, sub, stage));
+        dma16(s + oa[sub][1], dma_dst + unit_off(false, sub, stage) + 8192);
+    };
+    auto stage_b = [&](int sub, int stage, int kt) {
+        const unsigned char* s = sgpr_ptr(bbase + (size_t)kt * b_step);
+        dma16(s + ob[sub][0], dma_dst + unit_off(true, sub, stage));
+        dma16(s + ob[sub][1], dma_dst + unit_off(true, sub, stage) + 8192);
+    };
+
+    // ---- fragment read bases (per lane)
+    uint32_t ra[4], rb[4];
+    {
+        const int lr = lane & 31, g = lane >> 5;
+        const int t = ((lr >> 1) & 7) ^ g;
+        const int i = lane & 15, half = (lane >> 4) & 1;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if constexpr (!AMM) ra[ks] = (uint32_t)((wr * 64 + lr) * 128 + ((t << 4) ^ (ks << 5)));
+            if constexpr (!BMM) rb[ks] = (uint32_t)(65536 + (wc * 32 + lr) * 128 + ((t << 4) ^ (ks << 5)));
+        }
+        if constexpr (AMM) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const int c = wr * 8 + mb * 4 + half * 2 + ((i & 3) >> 1);
+                ra[mb] = (uint32_t)((g * 8 + (i >> 2)) * 256 + ((c ^ (4 * (i >> 2))) << 4) + (i & 1) * 8);
+            }
+            ra[2] = ra[3] = 0;
+        }
+        if constexpr (BMM) {
+            const int c = wc * 4 + half * 2 + ((i & 3) >> 1);
+            rb[0] = (uint32_t)(65536 + (g * 8 + (i >> 2)) * 256 + ((c ^ (4 * (i >> 2))) << 4) + (i & 1) * 8);
+            rb[1] = rb[2] = rb[3] = 0;
+        }
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    Frag4<AMM> fa0, fa1;
+    Frag4<BMM> fb0, fb1;
+
+    // the MFMA takes the B fragment first so that a lane ends up with ONE output row and 4-column runs (wide stores)
+#define G256_MMA(KS)                                                                                                     \
+    acc[mrow * 2 + 0][ncol] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr.template k<KS>(), fa0.template k<KS>(), acc[mrow * 2 + 0][ncol], 0, 0, 0); \
+    acc[mrow * 2 + 1][ncol] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr.template k<KS>(), fa1.template k<KS>(), acc[mrow * 2 + 1][ncol], 0, 0, 0);
+    auto mma_quad = [&](int mrow, int ncol, const Frag4<BMM>& bfr) {
+        __builtin_amdgcn_s_setprio(1);
+        G256_MMA(0) G256_MMA(1) G256_MMA(2) G256_MMA(3)
+        __builtin_amdgcn_s_setprio(0);
+    };
+#undef G256_MMA
+    auto bar = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto lwait = [&]() {
+        wait_lgkm0();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // DMA targets past the last tile are clamped to it: the unit lands in a slot nobody reads again, and the wait counts
+    // stay uniform (no tail variants of the loop body, which would make hipcc spill around the asm reads).
+    auto tile_body = [&](auto stage_c, int T) {
+        constexpr int S = decltype(stage_c)::value;
+        const int t1 = min(T + 1, nt - 1), t2 = min(T + 2, nt - 1);
+        // ---- phase 0: a0, b0
+        fa0.template read<unit_off(false, 0, S)>(ra, 0);
+        fa1.template read<unit_off(false, 0, S) + (AMM ? 0 : 4096)>(ra, 1);
+        fb0.template read<unit_off(true, 0, S) - 65536>(rb, 0);
+        stage_b(1, S ^ 1, t1);
+        wait_vm<8>();
+        bar(); lwait();
+        mma_quad(0, 0, fb0);
+        bar();
+        // ---- phase 1: b1
+        fb1.template read<unit_off(true, 1, S) - 65536>(rb, 0);
+        stage_a(1, S ^ 1, t1);
+        wait_vm<8>();
+        bar(); lwait();
+        mma_quad(0, 1, fb1);
+        bar();
+        // ---- phase 2: a1
+        fa0.template read<unit_off(false, 1, S)>(ra, 0);
+        fa1.template read<unit_off(false, 1, S) + (AMM ? 0 : 4096)>(ra, 1);
+        stage_a(0, S, t2);
+        wait_vm<8>();
+        bar(); lwait();
+        mma_quad(1, 1, fb1);
+        bar();
+        // ---- phase 3: nothing new to read
+        stage_b(0, S, t2);
+        wait_vm<8>();
+        bar();
+        mma_quad(1, 0, fb0);
+        bar();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // ---- prologue: tile 0 entirely, plus a0/b0 of tile 1   (nt is even and >= 2: see launch())
+    stage_a(0, 0, 0);
+    stage_b(0, 0, 0);
+    stage_b(1, 0, 0);
+    stage_a(1, 0, 0);
+    stage_a(0, 1, 1);
+    stage_b(0, 1, 1);
+    wait_vm<8>();
+    bar();
+    if (wr == 1) bar();   // lower wave row runs half a phase behind
+
+    for (int T = 0; T < nt; T += 2) {
+        tile_body(I0{}, T);
+        tile_body(I1{}, T + 1);
+    }
+    if (wr == 0) bar();
+    wait_vm<0>();          // the clamped tail DMAs must have landed before this workgroup's LDS is handed on
+
+    // ---- epilogue: lane owns row i, 4-column runs
+    const int lr = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int i = i0 + wr * 128 + (mb >> 1) * 64 + (mb & 1) * 32 + lr;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int j = j0 + wc * 64 + nb * 32 + q * 8 + g * 4;
+                const f32x16& c = acc[mb][nb];
+                epi(i, j, make_float4(c[q * 4 + 0], c[q * 4 + 1], c[q * 4 + 2], c[q * 4 + 3]), split);
+            }
+    }
+}
+
+static inline int per_split(int ktiles, int nsplit) {
+    int per = (ktiles + nsplit - 1) / nsplit;
+    return per + (per & 1);
+}
+template <bool AMM, bool BMM, class Epi>
+static int launch(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit,
+                  hipStream_t st) {
+    auto kern = gemm256_kernel<AMM, BMM, Epi>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const int ktiles = K / BK;
+    const int per = per_split(ktiles, nsplit);
+    const int splits = (ktiles + per - 1) / per;      // every split gets an even number (>= 2) of tiles
+    PA_LAUNCH(kern, dim3(tiles_m * tiles_n, splits), dim3(NT), LDS_BYTES, st, A, (uint32_t)lda, B, (uint32_t)ldb, epi, M, N,
+              ktiles, per, tiles_n);
+    return (int)hipGetLastError();
+}
+// shapes the kernel accepts; everything else stays on the generic engine (gemm_engine.h)
+static inline bool ok(int M, int N, int K, bool amm, bool bmm, size_t lda, size_t ldb) {
+    if (K % (2 * BK) || M < 8 || N < 8) return false;
+    if (amm && (M % 8)) return false;
+    if (bmm && (N % 8)) return false;
+    if ((lda % 8) || (ldb % 8)) return false;
+    // 32-bit byte offsets inside one operand
+    const size_t abytes = (amm ? (size_t)BK * lda + M : (size_t)M * lda) * 2, bbytes = (bmm ? (size_t)BK * ldb + N : (size_t)N * ldb) * 2;
+    return abytes < (1ull << 32) && bbytes < (1ull << 32);
+}
+static inline int splits_used(int K, int nsplit) {
+    const int ktiles = K / BK, per = per_split(ktiles, nsplit);
+    return (ktiles + per - 1) / per;
+}
+
+}   // namespace g256

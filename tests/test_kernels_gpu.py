@@ -73,6 +73,41 @@ def test_linear_backward(T, M, N, K):
     assert relerr(db, dy.double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(328, 264, 256), (256, 256, 128), (1568, 1024, 1024), (520, 776, 384), (3136, 3072, 1024)])
+def test_gemm256_fast_path(M, N, K):
+    """Shapes that take the 256x256 LDS-DMA bf16 kernel (csrc/gemm256.h): ragged M/N (clamped rows, masked stores), every
+    epilogue, K-major x K-major (forward), K-major x M-major (dgrad), M-major x M-major (wgrad, split over M)."""
+    T = torch.bfloat16
+    x = gen((M, K), 1, 1.0, T)
+    w = gen((N, K), 2, 0.05, T)
+    b = gen((N,), 3)
+    ref = x.float() @ w.float().t() + b
+    assert relerr(ops.linear_fwd(x, w, b, EPI_BIAS).float(), ref) < 1e-2
+    assert relerr(ops.linear_fwd(x, w, b, EPI_BIAS_F32), ref) < 2e-5 * math.sqrt(K)
+    act, pre = ops.linear_gelu(x, w, b)
+    assert relerr(pre.float(), ref) < 1e-2
+    assert relerr(act.float(), torch.nn.functional.gelu(pre.float())) < 1e-2
+    resid = gen((M, N), 4)
+    rowscale = gen(((M + 7) // 8,), 5).abs() + 0.5
+    out = ops.linear_fwd(x, w, b, EPI_BIAS_RESID, resid=resid, rowscale=rowscale, rows_per_sample=8)
+    assert relerr(out, resid + rowscale.repeat_interleave(8)[:M, None] * ref) < 2e-5 * math.sqrt(K)
+    # backward of a Linear(K2 -> N2) with contraction lengths that qualify: dgrad contracts over N2, wgrad over M2
+    M2, N2, K2 = (M // 128) * 128 if M >= 128 else 128, K, N
+    dy = gen((M2, N2), 6, 1.0, T)
+    w2 = gen((N2, K2), 7, 0.05, T)
+    x2 = gen((M2, K2), 8, 1.0, T)
+    pre2 = gen((M2, K2), 9, 1.0, T)
+    dx_ref = dy.float() @ w2.float()
+    assert relerr(ops.linear_dgrad(dy, w2).float(), dx_ref) < 1e-2
+    xg = pre2.float().clone().requires_grad_(True)
+    torch.nn.functional.gelu(xg).backward(torch.ones_like(xg))
+    assert relerr(ops.linear_dgrad(dy, w2, pre=pre2).float(), dx_ref * xg.grad) < 1e-2
+    dw = ops.linear_wgrad(dy, x2)
+    assert relerr(dw, dy.double().t() @ x2.double()) < 1e-4
+    # twice -> bit-identical (no atomics, fixed reduction order)
+    assert torch.equal(dw, ops.linear_wgrad(dy, x2))
+
+
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
 def test_linear_strided_views_and_pixshuf(T):
     """Column-slice inputs (tap concat buffer) and the decoder pixel-shuffle epilogue (models_painter.py:424-428)."""
