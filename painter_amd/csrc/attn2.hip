@@ -1,0 +1,616 @@
+// bf16 fused attention with decomposed rel-pos bias, second generation (forward, backward-dQ, backward-dKV).
+// Same math and same C ABI as attn_fwd.hip / attn_bwd.hip (Painter/models_painter.py:76-86, util/vitdet_utils.py:63-125,
+// SURVEY.md 8a a5-a8, a17, Appendix B.2); those files keep the exact-fp32 build and the shapes this file does not cover.
+//
+// What changed against generation 1, and why (rocprof: 1 workgroup of 4-7 waves per CU, 96-270 TFLOP/s):
+//   * LDS per query row drops from 672 B (two fp32 k-space tables) to 224 B: the kw table stays fp32 (it is loaded
+//     straight into the S accumulator as the MFMA's C operand -- no VALU add), the kh table is bf16 (one scalar per run of
+//     4 keys), and the bias GRADIENT needs no table at all (next point).  3 workgroups of 4 waves fit a CU.
+//   * d bias / d (kw), d bias / d (kh) are contractions of dS with one-hot key patterns, so they run on the matrix pipe:
+//     E^T[32][32 keys] . dS^T accumulates rows 0..Wp-1 = dGw[q][kw] over all key tiles and rows 28..31 = this tile's
+//     dGh[q][kh0..kh0+3]; the latter slide through a 4-deep register window (key rows are visited in order) and replace
+//     the consumed entries of the kh table in place.  No LDS atomics.
+//   * one LDS image per K / V / Q / dO tile: natural [row][64 d] order, XOR-swizzled so that BOTH the row-fragment
+//     ds_read_b128 (contraction over d) and the transposing ds_read_b64_tr_b16 (contraction over the tile's rows) are
+//     bank-conflict free.  No transposed copies, no register transposes.
+//   * forward: the running max is only re-based when a tile exceeds it by more than 2^6 (wave-uniform, rare branch), so
+//     the usual O rescale and the subtraction of the new max disappear from the per-tile VALU stream.
+// Work split (all three): workgroup = 4 waves, wave = 32 rows (queries, or keys in dKV), lane = one row end to end;
+// 32-row tiles of the other axis stream through LDS, register-staged (global -> VGPR early, VGPR -> LDS late), one
+// barrier per tile, double buffered.
+#include "attn_common.h"
+#include "../../include/painter_hip.h"
+#include "attn2.h"
+
+namespace a2 {
+
+constexpr int NW = 4, NT = 256, ROWS = 128, IMG = 4096, STAGE_QK = 2 * IMG;
+constexpr float THR = 6.0f;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+// ---- tile image: 32 rows x 128 B, 16-B chunk index XORed with a bijection of row bits 1..3
+DEVI int vsw(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
+
+struct Stager {   // one 32 x 64 bf16 tile, 256 threads, one 16-B chunk each
+    uint4 r;
+    DEVI void load(const bf16* src, size_t ld, int tid) { r = *reinterpret_cast<const uint4*>(src + (size_t)(tid >> 3) * ld + (tid & 7) * 8); }
+    DEVI void store(unsigned char* img, int tid) const {
+        const int row = tid >> 3, c = tid & 7;
+        *reinterpret_cast<uint4*>(img + row * 128 + ((c ^ vsw(row)) << 4)) = r;
+    }
+};
+
+// per-lane address pieces, computed once
+struct LaneAddr {
+    int rowbase, t;          // row fragment: byte = rowbase + (((2 s) ^ t) << 4)
+    int tr[2][2];            // transposed fragment: [dblk][lo/hi] byte offset for k-step 0; k-step 1 = + 2048
+    DEVI void init(int lane) {
+        const int row = lane & 31, g = lane >> 5;
+        rowbase = row * 128;
+        t = vsw(row) ^ g;
+        const int i = lane & 15, half = (lane >> 4) & 1;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi) {
+                const int r = 4 * g + (i >> 2) + 8 * hi;
+                const int chunk = 4 * db + 2 * half + ((i & 3) >> 1);
+                tr[db][hi] = r * 128 + ((chunk ^ vsw(r)) << 4) + (i & 1) * 8;
+            }
+    }
+};
+// A operand, rows = tile rows, contraction over d (k-step s of 16)
+DEVI bf16x8 rowfrag(const unsigned char* img, const LaneAddr& a, int s) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + a.rowbase + (((2 * s) ^ a.t) << 4)));
+}
+// A operand, rows = d (block db of 32), contraction over the tile's rows: slot t <-> row 16 s + 4 g + (t & 3) + 8 (t >> 2),
+// the order in which the MFMA D layout hands a lane its values (so D registers pack straight into the B operand)
+DEVI bf16x8 trfrag(const unsigned char* img, const LaneAddr& a, int db, int s) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a.tr[db][0] + s * 2048));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a.tr[db][1] + s * 2048));
+    const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(l, h, 0, 1, 2, 3));
+}
+DEVI bf16x8 gfrag(const bf16* p, int s, int g) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p + 16 * s + 8 * g)); }
+DEVI bf16x8 packfrag(const float* v) {
+    return __builtin_bit_cast(bf16x8, make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])));
+}
+DEVI f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+DEVI float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+DEVI float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+
+// k-space bias tables of this lane's query row:  tw[kw] = (q . rel_pos_w[qw - kw + Wp-1]) / scale   (fp32; C operand of S)
+//                                                th[kh] = (q . rel_pos_h[qh - kh + Hp-1]) * log2 e  (bf16)
+DEVI void build_tables(float* tw, bf16* th, const bf16* rcat, int NRP, const bf16x8 (&qf)[4], int qh, int qw, int Hp, int Wp,
+                       float inv_scale, int lane) {
+    const int g = lane >> 5;
+    for (int rbk = 0; rbk < NRP / 32; ++rbk) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const bf16* rp = rcat + (size_t)(rbk * 32 + (lane & 31)) * ATT_HD;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma(gfrag(rp, s, g), qf[s], acc);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = rbk * 32 + acc_row(reg, lane);
+            if (r < 2 * Hp - 1) {
+                const int kh = qh + Hp - 1 - r;
+                if (kh >= 0 && kh < Hp) th[kh] = (bf16)(acc[reg] * LOG2E_F);
+            } else {
+                const int rr = r - (2 * Hp - 1);
+                const int kw = qw + Wp - 1 - rr;
+                if (rr < 2 * Wp - 1 && kw >= 0 && kw < Wp) tw[kw] = acc[reg] * inv_scale;
+            }
+        }
+    }
+}
+
+// stage a wave's [d][row] accumulators (2 blocks of 32 d) as bf16 rows in LDS, then write whole 128-B rows
+DEVI void stage_rows(unsigned char* stg, const f32x16 (&acc)[2], float mul, int lane) {
+    const int g = lane >> 5;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int d0 = db * 32 + 8 * rg + 4 * g;
+            *reinterpret_cast<uint2*>(stg + (lane & 31) * 128 + d0 * 2) =
+                make_uint2(pack_bf16x2(acc[db][rg * 4] * mul, acc[db][rg * 4 + 1] * mul), pack_bf16x2(acc[db][rg * 4 + 2] * mul, acc[db][rg * 4 + 3] * mul));
+        }
+}
+DEVI void write_rows(const unsigned char* stg, bf16* dst, size_t ld, int lane) {   // dst = row 0 of the wave's 32 rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + 64 * i, row = c >> 3, ch = c & 7;
+        *reinterpret_cast<uint4*>(dst + (size_t)row * ld + ch * 8) = *reinterpret_cast<const uint4*>(stg + row * 128 + ch * 16);
+    }
+}
+
+// =============================================================================================== forward
+__global__ __launch_bounds__(NT) void fwd_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
+                                                  bf16* __restrict__ out, size_t ldo, float* __restrict__ lse, int L, int H, int Hp,
+                                                  int Wp, int NRP, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, row = wave * 32 + (lane & 31);
+    const int bh = blockIdx.y, b = bh / H, h = bh % H, D = H * ATT_HD;
+    const bf16* base = qkv + (size_t)b * L * ldq + h * ATT_HD;
+    const bf16* kbase = base + D;
+    const bf16* vbase = base + 2 * D;
+    const int qt = blockIdx.x * NW + wave;
+    const bool valid = qt * 32 < L;
+    const int q = qt * 32 + (lane & 31);
+    float* tw = reinterpret_cast<float*>(smem + 2 * STAGE_QK) + row * Wp;
+    bf16* th = reinterpret_cast<bf16*>(smem + 2 * STAGE_QK + ROWS * Wp * 4) + row * Hp;
+    LaneAddr la;
+    la.init(lane);
+
+    bf16x8 qf[4];
+    if (valid) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = gfrag(base + (size_t)q * ldq, s, g);
+        build_tables(tw, th, rcat, NRP, qf, q / Wp, q % Wp, Hp, Wp, 1.f / scale, lane);
+    }
+    Stager ks, vs;
+    const int ntile = L / 32;
+    ks.load(kbase, ldq, tid);
+    vs.load(vbase, ldq, tid);
+    ks.store(smem, tid);
+    vs.store(smem + IMG, tid);
+    __syncthreads();
+
+    f32x16 oacc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+    float m = 0.f, l = 0.f;
+    const float sl = scale * LOG2E_F;
+    int kh[4], kw[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int k0 = 8 * rg + 4 * g;
+        kh[rg] = k0 / Wp;
+        kw[rg] = k0 % Wp;
+    }
+    const int adv_h = 32 / Wp, adv_w = 32 % Wp;
+
+    for (int j = 0; j < ntile; ++j) {
+        if (j + 1 < ntile) {
+            ks.load(kbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
+            vs.load(vbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
+        }
+        const unsigned char* kimg = smem + (j & 1) * STAGE_QK;
+        const unsigned char* vimg = kimg + IMG;
+        if (valid) {
+            f32x16 sacc;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 bw = *reinterpret_cast<const float4*>(tw + kw[rg]);
+                sacc[rg * 4 + 0] = bw.x; sacc[rg * 4 + 1] = bw.y; sacc[rg * 4 + 2] = bw.z; sacc[rg * 4 + 3] = bw.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) sacc = mfma(rowfrag(kimg, la, s), qf[s], sacc);
+            float p[16];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float bhm = (float)th[kh[rg]] - m;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) p[rg * 4 + e] = fmaf(sacc[rg * 4 + e], sl, bhm);
+                tmax = fmaxf(tmax, fmaxf(fmaxf(p[rg * 4], p[rg * 4 + 1]), fmaxf(p[rg * 4 + 2], p[rg * 4 + 3])));
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            if (j == 0 || __any(tmax > THR)) {          // wave-uniform; after the first tiles almost never taken
+                const float delta = (j == 0) ? tmax : fmaxf(tmax, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m += delta;
+                l *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; p[r] -= delta; }
+            }
+            float rs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = __builtin_amdgcn_exp2f(p[r]);
+                rs += p[r];
+            }
+            l += rs;
+            const bf16x8 pf0 = packfrag(p), pf1 = packfrag(p + 8);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                oacc[db] = mfma(trfrag(vimg, la, db, 0), pf0, oacc[db]);
+                oacc[db] = mfma(trfrag(vimg, la, db, 1), pf1, oacc[db]);
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                kh[rg] += adv_h;
+                kw[rg] += adv_w;
+                if (kw[rg] >= Wp) { kw[rg] -= Wp; kh[rg] += 1; }
+            }
+        }
+        if (j + 1 < ntile) {
+            ks.store(smem + ((j + 1) & 1) * STAGE_QK, tid);
+            vs.store(smem + ((j + 1) & 1) * STAGE_QK + IMG, tid);
+        }
+        __syncthreads();
+    }
+    // the K/V stages are free now: per-wave 4 KB staging tile
+    unsigned char* stg = smem + wave * IMG;
+    if (valid) {
+        const float lt = l + __shfl_xor(l, 32, 64);
+        if (g == 0) lse[(size_t)bh * L + q] = (m + __builtin_amdgcn_logf(lt)) * LN2_F;
+        stage_rows(stg, oacc, 1.f / lt, lane);
+        write_rows(stg, out + (size_t)(b * L + qt * 32) * ldo + h * ATT_HD, ldo, lane);   // same-wave LDS ops are ordered
+    }
+}
+
+// =============================================================================================== backward: one-hot key patterns
+// etab[phase][s][g][row 32][8 slots] bf16: E^T[row][key] for the tile whose first key is 32*phase (mod Wp-periodic):
+//   row < Wp: 1 iff kw(key) == row;   row = 28 + i: 1 iff kh(key) - kh(first key of the tile) == i
+__global__ void etab_kernel(bf16* etab, int Wp, int nphase) {
+    const int phase = blockIdx.x;
+    const int off = (32 * phase) % Wp;
+    for (int idx = threadIdx.x; idx < 1024; idx += blockDim.x) {
+        const int slot = idx & 7, rrow = (idx >> 3) & 31, g = (idx >> 8) & 1, s = idx >> 9;
+        const int key = 16 * s + 4 * g + (slot & 3) + 8 * (slot >> 2);
+        const int a = off + key, kw = a % Wp, dk = a / Wp;
+        const bool one = rrow < Wp ? (kw == rrow) : (rrow >= 28 && dk == rrow - 28);
+        etab[(size_t)phase * 1024 + idx] = (bf16)(one ? 1.f : 0.f);
+    }
+}
+static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+static int etab_phases(int Wp) { return Wp / gcd_i(32, Wp); }
+constexpr int ETAB_BYTES = 32 * 2048;     // up to 32 phases
+
+// aux tile of (bh, q-tile), consumed by the dKV kernel with 16-byte reads:
+//   tabhT bf16 [Hp][32] | tabwT f32 [Wp][32] = tw[q][kw] - lse2[q] / (scale log2 e) | -Delta f32 [32]
+DEVI size_t aux_tile_bytes(int Hp, int Wp) { return (size_t)Hp * 64 + (size_t)Wp * 128 + 128; }
+
+// =============================================================================================== backward: dQ, bias gradients
+__global__ __launch_bounds__(NT) void bwd_dq_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
+                                                     const bf16* __restrict__ rcatT, const bf16* __restrict__ dout, size_t lddo,
+                                                     const float* __restrict__ lse, const float* __restrict__ delta,
+                                                     bf16* __restrict__ dqkv, bf16* __restrict__ dG, unsigned char* __restrict__ aux,
+                                                     int L, int H, int Hp, int Wp, int NRP, float scale, int nphase) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, row = wave * 32 + (lane & 31);
+    const int bh = blockIdx.y, b = bh / H, h = bh % H, D = H * ATT_HD;
+    const bf16* base = qkv + (size_t)b * L * ldq + h * ATT_HD;
+    const bf16* kbase = base + D;
+    const bf16* vbase = base + 2 * D;
+    const int qt = blockIdx.x * NW + wave;
+    const bool valid = qt * 32 < L;
+    const int q = qt * 32 + (lane & 31);
+    const int qh = q / Wp, qw = q % Wp;
+    float* tw = reinterpret_cast<float*>(smem + 2 * STAGE_QK) + row * Wp;
+    bf16* th = reinterpret_cast<bf16*>(smem + 2 * STAGE_QK + ROWS * Wp * 4) + row * Hp;
+    const bf16* etab = reinterpret_cast<const bf16*>(aux);
+    LaneAddr la;
+    la.init(lane);
+    const float sl = scale * LOG2E_F;
+
+    bf16x8 qf[4], dof[4];
+    float lse2 = 0.f, ndlt = 0.f;
+    if (valid) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = gfrag(base + (size_t)q * ldq, s, g);
+            dof[s] = gfrag(dout + (size_t)(b * L + q) * lddo + h * ATT_HD, s, g);
+        }
+        lse2 = lse[(size_t)bh * L + q] * LOG2E_F;
+        ndlt = -delta[(size_t)bh * L + q];
+        build_tables(tw, th, rcat, NRP, qf, qh, qw, Hp, Wp, 1.f / scale, lane);
+        // export the transposed tables for the dKV kernel (own-wave LDS writes above are ordered before these reads)
+        unsigned char* at = aux + ETAB_BYTES + ((size_t)bh * (L / 32) + qt) * aux_tile_bytes(Hp, Wp);
+        bf16* ahT = reinterpret_cast<bf16*>(at) + (lane & 31);
+        float* awT = reinterpret_cast<float*>(at + (size_t)Hp * 64) + (lane & 31);
+        const float ls = lse2 / sl;
+        for (int c = g; c < Hp; c += 2) ahT[(size_t)c * 32] = th[c];
+        for (int c = g; c < Wp; c += 2) awT[(size_t)c * 32] = tw[c] - ls;
+        if (g == 0) reinterpret_cast<float*>(at + (size_t)Hp * 64 + (size_t)Wp * 128)[lane & 31] = ndlt;
+    }
+    Stager ks, vs;
+    const int ntile = L / 32;
+    ks.load(kbase, ldq, tid);
+    vs.load(vbase, ldq, tid);
+    ks.store(smem, tid);
+    vs.store(smem + IMG, tid);
+    __syncthreads();
+
+    f32x16 dq[2], eacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; eacc[r] = 0.f; }
+    float wh[4] = {0.f, 0.f, 0.f, 0.f};
+    int kh[4], kw[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int k0 = 8 * rg + 4 * g;
+        kh[rg] = k0 / Wp;
+        kw[rg] = k0 % Wp;
+    }
+    const int adv_h = 32 / Wp, adv_w = 32 % Wp;
+    int kh0 = 0, phase = 0;
+
+    for (int j = 0; j < ntile; ++j) {
+        if (j + 1 < ntile) {
+            ks.load(kbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
+            vs.load(vbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
+        }
+        const unsigned char* kimg = smem + (j & 1) * STAGE_QK;
+        const unsigned char* vimg = kimg + IMG;
+        const int kh0n = (32 * (j + 1)) / Wp;
+        if (valid) {
+            const bf16* ep = etab + (size_t)phase * 1024 + (size_t)g * 256 + (lane & 31) * 8;
+            const bf16x8 ef0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ep));
+            const bf16x8 ef1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ep + 512));
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 bw = *reinterpret_cast<const float4*>(tw + kw[rg]);
+                sacc[rg * 4 + 0] = bw.x; sacc[rg * 4 + 1] = bw.y; sacc[rg * 4 + 2] = bw.z; sacc[rg * 4 + 3] = bw.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dpacc[r] = ndlt;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sacc = mfma(rowfrag(kimg, la, s), qf[s], sacc);
+                dpacc = mfma(rowfrag(vimg, la, s), dof[s], dpacc);
+            }
+            float ds[16];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float bhx = (float)th[kh[rg]] - lse2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    ds[rg * 4 + e] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + e], sl, bhx)) * dpacc[rg * 4 + e];
+            }
+            const bf16x8 dsf0 = packfrag(ds), dsf1 = packfrag(ds + 8);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                dq[db] = mfma(trfrag(kimg, la, db, 0), dsf0, dq[db]);
+                dq[db] = mfma(trfrag(kimg, la, db, 1), dsf1, dq[db]);
+            }
+            eacc = mfma(ef0, dsf0, eacc);
+            eacc = mfma(ef1, dsf1, eacc);
+            // rows 28..31 of eacc (registers 12..15 of the upper half-wave) are this tile's dGh[q][kh0 .. kh0+3]
+            if (g) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { wh[i] += eacc[12 + i]; eacc[12 + i] = 0.f; }
+                const int dlt = kh0n - kh0;             // 1..3 key rows completed by this tile (wave-uniform)
+                if (dlt >= 1 && kh0 < Hp) th[kh0] = (bf16)wh[0];
+                if (dlt >= 2 && kh0 + 1 < Hp) th[kh0 + 1] = (bf16)wh[1];
+                if (dlt >= 3 && kh0 + 2 < Hp) th[kh0 + 2] = (bf16)wh[2];
+                if (dlt == 1) { wh[0] = wh[1]; wh[1] = wh[2]; wh[2] = wh[3]; wh[3] = 0.f; }
+                else if (dlt == 2) { wh[0] = wh[2]; wh[1] = wh[3]; wh[2] = 0.f; wh[3] = 0.f; }
+                else if (dlt >= 3) { wh[0] = wh[3]; wh[1] = 0.f; wh[2] = 0.f; wh[3] = 0.f; }
+            }
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                kh[rg] += adv_h;
+                kw[rg] += adv_w;
+                if (kw[rg] >= Wp) { kw[rg] -= Wp; kh[rg] += 1; }
+            }
+        }
+        kh0 = kh0n;
+        phase = phase + 1 == nphase ? 0 : phase + 1;
+        if (j + 1 < ntile) {
+            ks.store(smem + ((j + 1) & 1) * STAGE_QK, tid);
+            vs.store(smem + ((j + 1) & 1) * STAGE_QK + IMG, tid);
+        }
+        __syncthreads();
+    }
+
+    unsigned char* stg = smem + wave * IMG;
+    if (valid) {
+        // the tables now become the k-space bias gradients: th[kh] = dGh (already, entry by entry), tw[kw] = dGw
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = acc_row(reg, lane);
+            if (r < Wp) tw[r] = eacc[reg];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[0][r] *= scale; dq[1][r] *= scale; }
+        // r-space: dG[q][r] gathers the tables; dQ^T[d][q] += sum_r Rcat[r][d] dG[q][r]; dG is also the operand of d rel_pos
+        bf16* dgrow = dG + ((size_t)(b * L + q) * H + h) * NRP;
+        for (int s = 0; s < NRP / 16; ++s) {
+            float gv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int r = 16 * s + 8 * g + t;
+                float v = 0.f;
+                if (r < 2 * Hp - 1) {
+                    const int khh = qh + Hp - 1 - r;
+                    if (khh >= 0 && khh < Hp) v = (float)th[khh];
+                } else {
+                    const int rr = r - (2 * Hp - 1);
+                    const int kww = qw + Wp - 1 - rr;
+                    if (rr < 2 * Wp - 1 && kww >= 0 && kww < Wp) v = tw[kww];
+                }
+                gv[t] = v;
+            }
+            const bf16x8 gf = packfrag(gv);
+            *reinterpret_cast<uint4*>(dgrow + 16 * s + 8 * g) = __builtin_bit_cast(uint4, gf);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                dq[db] = mfma(gfrag(rcatT + (size_t)(db * 32 + (lane & 31)) * NRP, s, g), gf, dq[db]);
+        }
+        stage_rows(stg, dq, 1.f, lane);
+        write_rows(stg, dqkv + (size_t)(b * L + qt * 32) * ldq + h * ATT_HD, ldq, lane);
+    }
+}
+
+// =============================================================================================== backward: dK, dV
+constexpr int AH_LD = 80, AW_LD = 144;     // LDS row strides (bytes) of the transposed kh (bf16) / kw (f32) tables
+__global__ __launch_bounds__(NT) void bwd_dkv_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ dout,
+                                                      size_t lddo, const unsigned char* __restrict__ aux, bf16* __restrict__ dqkv,
+                                                      int L, int H, int Hp, int Wp, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H, D = H * ATT_HD;
+    const bf16* qbase = qkv + (size_t)b * L * ldq + h * ATT_HD;
+    const bf16* dobase = dout + (size_t)b * L * lddo + h * ATT_HD;
+    const int kt = blockIdx.x * NW + wave;
+    const bool valid = kt * 32 < L;
+    const int key = kt * 32 + (lane & 31);
+    const int khl = key / Wp, kwl = key % Wp;
+    const int stage_bytes = STAGE_QK + Hp * AH_LD + Wp * AW_LD + 128;
+    const int n_h = Hp * 4, n_w = Wp * 8, n_aux = n_h + n_w + 8;       // 16-byte chunks of the aux tile
+    const size_t atb = aux_tile_bytes(Hp, Wp);
+    const unsigned char* aux_bh = aux + ETAB_BYTES + (size_t)bh * (L / 32) * atb;
+    LaneAddr la;
+    la.init(lane);
+    const float sl = scale * LOG2E_F;
+
+    bf16x8 kf[4], vf[4];
+    if (valid) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = gfrag(qbase + D + (size_t)key * ldq, s, g);
+            vf[s] = gfrag(qbase + 2 * D + (size_t)key * ldq, s, g);
+        }
+    }
+    Stager qs, dos;
+    uint4 ra0, ra1, ra2;      // aux tile chunks (named registers: an indexed array would live in scratch)
+    const int ntile = L / 32;
+    auto aux_store = [&](unsigned char* ah, unsigned char* aw, int c, const uint4& v) {
+        if (c < n_h) *reinterpret_cast<uint4*>(ah + (c >> 2) * AH_LD + (c & 3) * 16) = v;
+        else if (c < n_h + n_w) *reinterpret_cast<uint4*>(aw + ((c - n_h) >> 3) * AW_LD + ((c - n_h) & 7) * 16) = v;
+        else if (c < n_aux) *reinterpret_cast<uint4*>(aw + Wp * AW_LD + (c - n_h - n_w) * 16) = v;
+    };
+    auto load_all = [&](int j) {
+        qs.load(qbase + (size_t)j * 32 * ldq, ldq, tid);
+        dos.load(dobase + (size_t)j * 32 * lddo, lddo, tid);
+        const unsigned char* at = aux_bh + (size_t)j * atb;
+        if (tid < n_aux) ra0 = *reinterpret_cast<const uint4*>(at + (size_t)tid * 16);
+        if (tid + NT < n_aux) ra1 = *reinterpret_cast<const uint4*>(at + (size_t)(tid + NT) * 16);
+        if (tid + 2 * NT < n_aux) ra2 = *reinterpret_cast<const uint4*>(at + (size_t)(tid + 2 * NT) * 16);
+    };
+    auto store_all = [&](int stage) {
+        unsigned char* s0 = smem + stage * stage_bytes;
+        qs.store(s0, tid);
+        dos.store(s0 + IMG, tid);
+        unsigned char* ah = s0 + STAGE_QK;
+        unsigned char* aw = ah + Hp * AH_LD;
+        aux_store(ah, aw, tid, ra0);
+        aux_store(ah, aw, tid + NT, ra1);
+        aux_store(ah, aw, tid + 2 * NT, ra2);
+    };
+    load_all(0);
+    store_all(0);
+    __syncthreads();
+
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+
+    for (int j = 0; j < ntile; ++j) {
+        if (j + 1 < ntile) load_all(j + 1);
+        const unsigned char* qimg = smem + (j & 1) * stage_bytes;
+        const unsigned char* doimg = qimg + IMG;
+        if (valid) {
+            const unsigned char* ah = qimg + STAGE_QK + khl * AH_LD;
+            const unsigned char* aw = qimg + STAGE_QK + Hp * AH_LD + kwl * AW_LD;
+            const unsigned char* ad = qimg + STAGE_QK + Hp * AH_LD + Wp * AW_LD;
+            f32x16 sacc, dpacc;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int q0 = 8 * rg + 4 * g;
+                const float4 bw = *reinterpret_cast<const float4*>(aw + q0 * 4);
+                const float4 nd = *reinterpret_cast<const float4*>(ad + q0 * 4);
+                sacc[rg * 4 + 0] = bw.x; sacc[rg * 4 + 1] = bw.y; sacc[rg * 4 + 2] = bw.z; sacc[rg * 4 + 3] = bw.w;
+                dpacc[rg * 4 + 0] = nd.x; dpacc[rg * 4 + 1] = nd.y; dpacc[rg * 4 + 2] = nd.z; dpacc[rg * 4 + 3] = nd.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sacc = mfma(rowfrag(qimg, la, s), kf[s], sacc);          // S[q][key]: lane = key, registers = q rows
+                dpacc = mfma(rowfrag(doimg, la, s), vf[s], dpacc);       // dP[q][key] - Delta[q]
+            }
+            float p[16], ds[16];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const uint2 b4 = *reinterpret_cast<const uint2*>(ah + (8 * rg + 4 * g) * 2);
+                p[rg * 4 + 0] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 0], sl, bf_lo(b4.x)));
+                p[rg * 4 + 1] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 1], sl, bf_hi(b4.x)));
+                p[rg * 4 + 2] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 2], sl, bf_lo(b4.y)));
+                p[rg * 4 + 3] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 3], sl, bf_hi(b4.y)));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ds[rg * 4 + e] = p[rg * 4 + e] * dpacc[rg * 4 + e];
+            }
+            const bf16x8 pf0 = packfrag(p), pf1 = packfrag(p + 8), dsf0 = packfrag(ds), dsf1 = packfrag(ds + 8);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                dv[db] = mfma(trfrag(doimg, la, db, 0), pf0, dv[db]);    // dV^T[d][key] += dO^T[d][q] P[q][key]
+                dv[db] = mfma(trfrag(doimg, la, db, 1), pf1, dv[db]);
+                dk[db] = mfma(trfrag(qimg, la, db, 0), dsf0, dk[db]);    // dK^T[d][key] += Q^T[d][q] dS[q][key]
+                dk[db] = mfma(trfrag(qimg, la, db, 1), dsf1, dk[db]);
+            }
+        }
+        if (j + 1 < ntile) store_all((j + 1) & 1);
+        __syncthreads();
+    }
+    unsigned char* stg = smem + wave * 2 * IMG;
+    if (valid) {
+        stage_rows(stg, dk, scale, lane);
+        stage_rows(stg + IMG, dv, 1.f, lane);
+        bf16* orow = dqkv + (size_t)(b * L + kt * 32) * ldq + h * ATT_HD;
+        write_rows(stg, orow + D, ldq, lane);
+        write_rows(stg + IMG, orow + 2 * D, ldq, lane);
+    }
+}
+
+static int set_smem(const void* kern, bool& done) {
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    return 0;
+}
+
+}   // namespace a2
+
+bool attn2_ok(int L, int Hp, int Wp) { return L == Hp * Wp && L % 32 == 0 && Wp % 4 == 0 && Wp >= 12 && Wp <= 28 && Hp % 2 == 0 && Hp >= 2; }
+
+int attn2_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t ldo, float* lse, int Bn, int L, int H, int Hp, int Wp,
+              float scale, hipStream_t st) {
+    using namespace a2;
+    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    const size_t smem = 2 * STAGE_QK + (size_t)ROWS * (Wp * 4 + Hp * 2);
+    static bool done = false;
+    if (int e = set_smem(reinterpret_cast<const void*>(fwd_kernel), done)) return e;
+    PA_LAUNCH(fwd_kernel, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, out, (size_t)ldo, lse, L, H, Hp,
+              Wp, NRP, scale);
+    return (int)hipGetLastError();
+}
+
+int64_t attn2_aux_bytes(int Bn, int L, int H, int Hp, int Wp) {
+    return (int64_t)a2::ETAB_BYTES + (int64_t)Bn * H * (L / 32) * ((int64_t)Hp * 64 + (int64_t)Wp * 128 + 128);
+}
+
+int attn2_bwd(const bf16* qkv, int64_t ldq, const bf16* rcat, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse,
+              const float* delta, bf16* dqkv, bf16* dG, void* aux, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st) {
+    using namespace a2;
+    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    const int nphase = etab_phases(Wp);
+    PA_LAUNCH(etab_kernel, dim3(nphase), dim3(256), 0, st, reinterpret_cast<bf16*>(aux), Wp, nphase);
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    {
+        const size_t smem = 2 * STAGE_QK + (size_t)ROWS * (Wp * 4 + Hp * 2);
+        static bool done = false;
+        if ((e = set_smem(reinterpret_cast<const void*>(bwd_dq_kernel), done))) return e;
+        PA_LAUNCH(bwd_dq_kernel, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, rcatT, dout, (size_t)lddo,
+                  lse, delta, dqkv, dG, reinterpret_cast<unsigned char*>(aux), L, H, Hp, Wp, NRP, scale, nphase);
+        if ((e = (int)hipGetLastError())) return e;
+    }
+    {
+        size_t smem = 2 * (size_t)(STAGE_QK + Hp * AH_LD + Wp * AW_LD + 128);
+        if (smem < (size_t)NW * 2 * IMG) smem = (size_t)NW * 2 * IMG;
+        if (Hp * 4 + Wp * 8 + 8 > 3 * NT) return (int)hipErrorInvalidValue;
+        static bool done = false;
+        if ((e = set_smem(reinterpret_cast<const void*>(bwd_dkv_kernel), done))) return e;
+        PA_LAUNCH(bwd_dkv_kernel, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, dout, (size_t)lddo,
+                  reinterpret_cast<const unsigned char*>(aux), dqkv, L, H, Hp, Wp, scale);
+        return (int)hipGetLastError();
+    }
+}

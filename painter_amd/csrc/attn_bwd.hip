@@ -13,6 +13,7 @@
 #include "attn_common.h"
 #include "gemm_engine.h"
 #include "../../include/painter_hip.h"
+#include "attn2.h"
 
 // ------------------------------------------------------------------------------- Delta pre-pass
 template <typename T> __global__ void attn_delta_kernel(const T* o, size_t ldo, const T* d_o, size_t lddo, float* delta, int R, int L, int H) {
@@ -417,7 +418,9 @@ extern "C" int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* 
 }
 
 extern "C" int64_t pa_attn_bwd_aux_bytes(int batch, int L, int heads, int Hp, int Wp) {
-    return (int64_t)batch * heads * (L / 32) * (Hp + Wp + 2) * 32 * sizeof(float);
+    const int64_t gen1 = (int64_t)batch * heads * (L / 32) * (Hp + Wp + 2) * 32 * sizeof(float);
+    const int64_t gen2 = attn2_ok(L, Hp, Wp) ? attn2_aux_bytes(batch, L, heads, Hp, Wp) : 0;
+    return gen1 > gen2 ? gen1 : gen2;
 }
 
 template <typename T>
@@ -472,6 +475,9 @@ extern "C" int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* 
                            const float* lse, const float* delta, void* dqkv, void* dG, void* aux, int batch, int L, int heads, int Hp,
                            int Wp, float scale, hipStream_t st) {
     if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4) return (int)hipErrorInvalidValue;
+    if (dtype == PA_BF16 && attn2_ok(L, Hp, Wp))
+        return attn2_bwd((const bf16*)qkv, ldq, (const bf16*)rcat, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, (bf16*)dqkv,
+                         (bf16*)dG, aux, batch, L, heads, Hp, Wp, scale, st);
     if (dtype == PA_BF16)
         return attn_bwd_t<bf16>((const bf16*)qkv, ldq, (const bf16*)rcat, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta,
                                 (bf16*)dqkv, (bf16*)dG, (float*)aux, batch, L, heads, Hp, Wp, scale, st);

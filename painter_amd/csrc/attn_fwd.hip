@@ -11,6 +11,7 @@
 // K/V tiles of 32 keys are staged global -> registers -> swizzled LDS, double buffered, one barrier per tile.
 #include "attn_common.h"
 #include "../../include/painter_hip.h"
+#include "attn2.h"
 
 template <typename T, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__ qkv, size_t ldq, const T* __restrict__ rcat,
@@ -209,6 +210,8 @@ extern "C" int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* 
                            int batch, int L, int heads, int Hp, int Wp, float scale, hipStream_t st) {
     if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4 || 32 % 4) return (int)hipErrorInvalidValue;
     const bool seven = ((L / 32) % 7 == 0);
+    if (dtype == PA_BF16 && attn2_ok(L, Hp, Wp))
+        return attn2_fwd((const bf16*)qkv, ldq, (const bf16*)rcat, (bf16*)out, ldo, lse, batch, L, heads, Hp, Wp, scale, st);
     if (dtype == PA_BF16) {
         if (seven) return attn_fwd_launch<bf16, 7>((const bf16*)qkv, ldq, (const bf16*)rcat, (bf16*)out, ldo, lse, batch, L, heads, Hp, Wp, scale, st);
         return attn_fwd_launch<bf16, 4>((const bf16*)qkv, ldq, (const bf16*)rcat, (bf16*)out, ldo, lse, batch, L, heads, Hp, Wp, scale, st);

@@ -171,7 +171,8 @@ def attn_reference(qkv, rel_h, rel_w, B, L, H, Hp, Wp, scale):
 
 
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,Hp,Wp", [(1, 2, 8, 4), (2, 2, 56, 28), (1, 1, 16, 8)])
+@pytest.mark.parametrize("B,H,Hp,Wp", [(1, 2, 8, 4), (2, 2, 56, 28), (1, 1, 16, 8), (1, 2, 8, 12), (2, 1, 8, 20), (1, 2, 16, 16),
+                                        (1, 1, 8, 24), (1, 3, 16, 28)])
 def test_attn_fwd(T, B, H, Hp, Wp):
     L = Hp * Wp
     qkv = gen((B * L, 3 * H * 64), 1, 1.0, T)
@@ -187,7 +188,8 @@ def test_attn_fwd(T, B, H, Hp, Wp):
 
 
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,Hp,Wp", [(1, 2, 8, 4), (2, 2, 56, 28), (3, 1, 16, 8)])
+@pytest.mark.parametrize("B,H,Hp,Wp", [(1, 2, 8, 4), (2, 2, 56, 28), (3, 1, 16, 8), (1, 2, 8, 12), (2, 1, 8, 20), (1, 2, 16, 16),
+                                        (1, 1, 8, 24), (1, 3, 16, 28)])
 def test_attn_bwd(T, B, H, Hp, Wp):
     L = Hp * Wp
     nh, nw = 2 * Hp - 1, 2 * Wp - 1
@@ -226,6 +228,23 @@ def test_attn_fwd_spiked_key_online_softmax():
     out, lse = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125)
     ref, lse_ref = attn_reference(qkv, rel[0], rel[1], B, L, H, Hp, Wp, 0.125)
     assert relerr(out, ref) < 2e-5 and relerr(lse, lse_ref) < 1e-5
+
+
+def test_attn2_bf16_spiked_key_rebase():
+    """bf16 generation-2 forward: the running max is re-based only when a tile exceeds it by > 2^6; force that late."""
+    B, H, Hp, Wp = 1, 1, 8, 16
+    L = Hp * Wp
+    qkv = gen((B * L, 3 * 64), 7, 0.5)
+    qkv[5, 0:64] = 3.0
+    qkv[100, 64:128] = 3.0        # logit spike 0.125 * 9 * 64 = 72 in the last key tile
+    qkv[37, 0:64] = -2.0
+    qkv[70, 64:128] = -2.0        # and a smaller one (32) in tile 2
+    qkv = qkv.to(torch.bfloat16)
+    rel_h, rel_w = gen((2 * Hp - 1, 64), 2, 0.2), gen((2 * Wp - 1, 64), 3, 0.2)
+    rcat = ops.relpos_pack(rel_h, rel_w, Hp, Wp, torch.bfloat16)
+    out, lse = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125)
+    ref, lse_ref = attn_reference(qkv, rcat[: 2 * Hp - 1], rcat[2 * Hp - 1: 2 * Hp + 2 * Wp - 2], B, L, H, Hp, Wp, 0.125)
+    assert relerr(out.float(), ref) < 2e-2 and relerr(lse, lse_ref) < 2e-3
 
 
 def test_determinism_same_input_bit_identical():
