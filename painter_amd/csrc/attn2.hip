@@ -21,6 +21,7 @@
 #include "attn_common.h"
 #include "../../include/painter_hip.h"
 #include "attn2.h"
+#include <cstdlib>
 
 namespace a2 {
 
@@ -74,8 +75,38 @@ DEVI bf16x8 trfrag(const unsigned char* img, const LaneAddr& a, int db, int s) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(l, h, 0, 1, 2, 3));
 }
 DEVI bf16x8 gfrag(const bf16* p, int s, int g) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p + 16 * s + 8 * g)); }
-DEVI bf16x8 packfrag(const float* v) {
-    return __builtin_bit_cast(bf16x8, make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])));
+typedef __attribute__((ext_vector_type(8))) float f32x8;
+DEVI bf16x8 packfrag(const float* v) {      // one v_cvt_pk_bf16_f32 per pair
+    const f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+    return __builtin_convertvector(f, bf16x8);
+}
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// exchange with the lane 32 away (the other half of this row's key runs): VALU permlane, no LDS round trip
+DEVI float xor32(float v) {
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+DEVI float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+DEVI float max16(const float* p) {
+    const float a = max3f(p[0], p[1], p[2]), b = max3f(p[3], p[4], p[5]), c = max3f(p[6], p[7], p[8]), d = max3f(p[9], p[10], p[11]),
+                e = max3f(p[12], p[13], p[14]);
+    return max3f(max3f(a, b, c), max3f(d, e, p[15]), -INFINITY);
+}
+DEVI float sum16(const float* p) {      // packed adds
+    f32x2 a = {p[0], p[1]}, b = {p[2], p[3]}, c = {p[4], p[5]}, d = {p[6], p[7]};
+    a += f32x2{p[8], p[9]}; b += f32x2{p[10], p[11]}; c += f32x2{p[12], p[13]}; d += f32x2{p[14], p[15]};
+    a += b; c += d; a += c;
+    return a[0] + a[1];
+}
+// run table: for tile phase ph, half-wave g, run rg: low 16 bits = kw * 4 (byte offset into the lane's kw table row),
+// high 16 bits = (kh - kh0(tile)) * 2 (byte offset into the kh table row, relative to the tile's first key row)
+DEVI void build_rtab(uint32_t* rtab, int nphase, int Wp, int tid) {
+    if (tid < nphase * 8) {
+        const int ph = tid >> 3, g = (tid >> 2) & 1, rg = tid & 3;
+        const int a = (32 * ph) % Wp + 8 * rg + 4 * g;
+        rtab[tid] = (uint32_t)((a % Wp) * 4) | ((uint32_t)((a / Wp) * 2) << 16);
+    }
 }
 DEVI f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 DEVI float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
@@ -129,9 +160,10 @@ DEVI void write_rows(const unsigned char* stg, bf16* dst, size_t ld, int lane) {
 }
 
 // =============================================================================================== forward
-__global__ __launch_bounds__(NT) void fwd_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
+// LDS: [K img | V img] x 2 stages (16 KB) | tw f32 [128][Wp] | th bf16 [128][thld] | run table [nphase][2][4] u32
+__global__ __launch_bounds__(NT, 2) void fwd_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
                                                   bf16* __restrict__ out, size_t ldo, float* __restrict__ lse, int L, int H, int Hp,
-                                                  int Wp, int NRP, float scale) {
+                                                  int Wp, int NRP, float scale, int thld, int nphase) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, row = wave * 32 + (lane & 31);
     const int bh = blockIdx.y, b = bh / H, h = bh % H, D = H * ATT_HD;
@@ -141,16 +173,18 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const bf16* __restrict__ qkv, s
     const int qt = blockIdx.x * NW + wave;
     const bool valid = qt * 32 < L;
     const int q = qt * 32 + (lane & 31);
-    float* tw = reinterpret_cast<float*>(smem + 2 * STAGE_QK) + row * Wp;
-    bf16* th = reinterpret_cast<bf16*>(smem + 2 * STAGE_QK + ROWS * Wp * 4) + row * Hp;
+    unsigned char* twb = smem + 2 * STAGE_QK + (size_t)row * Wp * 4;
+    unsigned char* thb = smem + 2 * STAGE_QK + ROWS * Wp * 4 + (size_t)row * thld * 2;
+    uint32_t* rtab = reinterpret_cast<uint32_t*>(smem + 2 * STAGE_QK + ROWS * Wp * 4 + ROWS * thld * 2);
     LaneAddr la;
     la.init(lane);
+    build_rtab(rtab, nphase, Wp, tid);
 
     bf16x8 qf[4];
     if (valid) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = gfrag(base + (size_t)q * ldq, s, g);
-        build_tables(tw, th, rcat, NRP, qf, q / Wp, q % Wp, Hp, Wp, 1.f / scale, lane);
+        build_tables(reinterpret_cast<float*>(twb), reinterpret_cast<bf16*>(thb), rcat, NRP, qf, q / Wp, q % Wp, Hp, Wp, 1.f / scale, lane);
     }
     Stager ks, vs;
     const int ntile = L / 32;
@@ -165,14 +199,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const bf16* __restrict__ qkv, s
     for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
     float m = 0.f, l = 0.f;
     const float sl = scale * LOG2E_F;
-    int kh[4], kw[4];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-        const int k0 = 8 * rg + 4 * g;
-        kh[rg] = k0 / Wp;
-        kw[rg] = k0 % Wp;
-    }
-    const int adv_h = 32 / Wp, adv_w = 32 % Wp;
+    int phase = 0;
 
     for (int j = 0; j < ntile; ++j) {
         if (j + 1 < ntile) {
@@ -182,24 +209,26 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const bf16* __restrict__ qkv, s
         const unsigned char* kimg = smem + (j & 1) * STAGE_QK;
         const unsigned char* vimg = kimg + IMG;
         if (valid) {
+            const uint4 rt = *reinterpret_cast<const uint4*>(rtab + (phase * 2 + g) * 4);
+            const uint32_t rts[4] = {rt.x, rt.y, rt.z, rt.w};
+            const unsigned char* tht = thb + ((32 * j) / Wp) * 2;
             f32x16 sacc;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const float4 bw = *reinterpret_cast<const float4*>(tw + kw[rg]);
+                const float4 bw = *reinterpret_cast<const float4*>(twb + (rts[rg] & 0xffffu));
                 sacc[rg * 4 + 0] = bw.x; sacc[rg * 4 + 1] = bw.y; sacc[rg * 4 + 2] = bw.z; sacc[rg * 4 + 3] = bw.w;
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) sacc = mfma(rowfrag(kimg, la, s), qf[s], sacc);
             float p[16];
-            float tmax = -INFINITY;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const float bhm = (float)th[kh[rg]] - m;
+                const float bhm = (float)*reinterpret_cast<const bf16*>(tht + (rts[rg] >> 16)) - m;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) p[rg * 4 + e] = fmaf(sacc[rg * 4 + e], sl, bhm);
-                tmax = fmaxf(tmax, fmaxf(fmaxf(p[rg * 4], p[rg * 4 + 1]), fmaxf(p[rg * 4 + 2], p[rg * 4 + 3])));
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            float tmax = max16(p);
+            tmax = fmaxf(tmax, xor32(tmax));
             if (j == 0 || __any(tmax > THR)) {          // wave-uniform; after the first tiles almost never taken
                 const float delta = (j == 0) ? tmax : fmaxf(tmax, 0.f);
                 const float alpha = __builtin_amdgcn_exp2f(-delta);
@@ -208,26 +237,17 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const bf16* __restrict__ qkv, s
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; p[r] -= delta; }
             }
-            float rs = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                p[r] = __builtin_amdgcn_exp2f(p[r]);
-                rs += p[r];
-            }
-            l += rs;
+            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(p[r]);
+            l += sum16(p);
             const bf16x8 pf0 = packfrag(p), pf1 = packfrag(p + 8);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 oacc[db] = mfma(trfrag(vimg, la, db, 0), pf0, oacc[db]);
                 oacc[db] = mfma(trfrag(vimg, la, db, 1), pf1, oacc[db]);
             }
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                kh[rg] += adv_h;
-                kw[rg] += adv_w;
-                if (kw[rg] >= Wp) { kw[rg] -= Wp; kh[rg] += 1; }
-            }
         }
+        phase = phase + 1 == nphase ? 0 : phase + 1;
         if (j + 1 < ntile) {
             ks.store(smem + ((j + 1) & 1) * STAGE_QK, tid);
             vs.store(smem + ((j + 1) & 1) * STAGE_QK + IMG, tid);
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(NT) void fwd_kernel(const bf16* __restrict__ qkv, s
     // the K/V stages are free now: per-wave 4 KB staging tile
     unsigned char* stg = smem + wave * IMG;
     if (valid) {
-        const float lt = l + __shfl_xor(l, 32, 64);
+        const float lt = l + xor32(l);
         if (g == 0) lse[(size_t)bh * L + q] = (m + __builtin_amdgcn_logf(lt)) * LN2_F;
         stage_rows(stg, oacc, 1.f / lt, lane);
         write_rows(stg, out + (size_t)(b * L + qt * 32) * ldo + h * ATT_HD, ldo, lane);   // same-wave LDS ops are ordered
@@ -263,15 +283,17 @@ static int etab_phases(int Wp) { return Wp / gcd_i(32, Wp); }
 constexpr int ETAB_BYTES = 32 * 2048;     // up to 32 phases
 
 // aux tile of (bh, q-tile), consumed by the dKV kernel with 16-byte reads:
-//   tabhT bf16 [Hp][32] | tabwT f32 [Wp][32] = tw[q][kw] - lse2[q] / (scale log2 e) | -Delta f32 [32]
-DEVI size_t aux_tile_bytes(int Hp, int Wp) { return (size_t)Hp * 64 + (size_t)Wp * 128 + 128; }
+//   tabhT f32 [Hp][32] (the bf16-rounded values the other kernels use) | tabwT f32 [Wp][32] = tw[q][kw] - lse2[q] / (scale log2 e)
+//   | -Delta f32 [32]
+DEVI size_t aux_tile_bytes(int Hp, int Wp) { return (size_t)(Hp + Wp) * 128 + 128; }
 
 // =============================================================================================== backward: dQ, bias gradients
-__global__ __launch_bounds__(NT) void bwd_dq_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
+template <int MINW>
+__global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
                                                      const bf16* __restrict__ rcatT, const bf16* __restrict__ dout, size_t lddo,
                                                      const float* __restrict__ lse, const float* __restrict__ delta,
                                                      bf16* __restrict__ dqkv, bf16* __restrict__ dG, unsigned char* __restrict__ aux,
-                                                     int L, int H, int Hp, int Wp, int NRP, float scale, int nphase) {
+                                                     int L, int H, int Hp, int Wp, int NRP, float scale, int thld, int nphase) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, row = wave * 32 + (lane & 31);
     const int bh = blockIdx.y, b = bh / H, h = bh % H, D = H * ATT_HD;
@@ -282,15 +304,25 @@ __global__ __launch_bounds__(NT) void bwd_dq_kernel(const bf16* __restrict__ qkv
     const bool valid = qt * 32 < L;
     const int q = qt * 32 + (lane & 31);
     const int qh = q / Wp, qw = q % Wp;
-    float* tw = reinterpret_cast<float*>(smem + 2 * STAGE_QK) + row * Wp;
-    bf16* th = reinterpret_cast<bf16*>(smem + 2 * STAGE_QK + ROWS * Wp * 4) + row * Hp;
-    const bf16* etab = reinterpret_cast<const bf16*>(aux);
+    unsigned char* twb = smem + 2 * STAGE_QK + (size_t)row * Wp * 4;
+    unsigned char* thb = smem + 2 * STAGE_QK + ROWS * Wp * 4 + (size_t)row * thld * 2;
+    float* tw = reinterpret_cast<float*>(twb);
+    bf16* th = reinterpret_cast<bf16*>(thb);
+    uint32_t* rtab = reinterpret_cast<uint32_t*>(smem + 2 * STAGE_QK + ROWS * Wp * 4 + ROWS * thld * 2);
+    // one-hot key patterns of every tile phase, copied once into LDS (a per-tile global load would sit on the critical path)
+    unsigned char* etab = reinterpret_cast<unsigned char*>(rtab) + 1024;
+    for (int c = tid; c < nphase * 128; c += NT)
+        *reinterpret_cast<uint4*>(etab + c * 16) = *reinterpret_cast<const uint4*>(aux + (size_t)c * 16);
     LaneAddr la;
     la.init(lane);
+    build_rtab(rtab, nphase, Wp, tid);
     const float sl = scale * LOG2E_F;
 
     bf16x8 qf[4], dof[4];
-    float lse2 = 0.f, ndlt = 0.f;
+    float lse2 = 0.f;
+    f32x16 ndl;              // -Delta[q] in every register: C operand of the first dP MFMA, so dpacc = dP - Delta for free
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ndl[r] = 0.f;
     if (valid) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -298,16 +330,18 @@ __global__ __launch_bounds__(NT) void bwd_dq_kernel(const bf16* __restrict__ qkv
             dof[s] = gfrag(dout + (size_t)(b * L + q) * lddo + h * ATT_HD, s, g);
         }
         lse2 = lse[(size_t)bh * L + q] * LOG2E_F;
-        ndlt = -delta[(size_t)bh * L + q];
+        const float ndlt = -delta[(size_t)bh * L + q];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ndl[r] = ndlt;
         build_tables(tw, th, rcat, NRP, qf, qh, qw, Hp, Wp, 1.f / scale, lane);
         // export the transposed tables for the dKV kernel (own-wave LDS writes above are ordered before these reads)
         unsigned char* at = aux + ETAB_BYTES + ((size_t)bh * (L / 32) + qt) * aux_tile_bytes(Hp, Wp);
-        bf16* ahT = reinterpret_cast<bf16*>(at) + (lane & 31);
-        float* awT = reinterpret_cast<float*>(at + (size_t)Hp * 64) + (lane & 31);
+        float* ahT = reinterpret_cast<float*>(at) + (lane & 31);
+        float* awT = reinterpret_cast<float*>(at + (size_t)Hp * 128) + (lane & 31);
         const float ls = lse2 / sl;
-        for (int c = g; c < Hp; c += 2) ahT[(size_t)c * 32] = th[c];
+        for (int c = g; c < Hp; c += 2) ahT[(size_t)c * 32] = (float)th[c];
         for (int c = g; c < Wp; c += 2) awT[(size_t)c * 32] = tw[c] - ls;
-        if (g == 0) reinterpret_cast<float*>(at + (size_t)Hp * 64 + (size_t)Wp * 128)[lane & 31] = ndlt;
+        if (g == 0) reinterpret_cast<float*>(at + (size_t)(Hp + Wp) * 128)[lane & 31] = ndlt;
     }
     Stager ks, vs;
     const int ntile = L / 32;
@@ -321,14 +355,6 @@ __global__ __launch_bounds__(NT) void bwd_dq_kernel(const bf16* __restrict__ qkv
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; eacc[r] = 0.f; }
     float wh[4] = {0.f, 0.f, 0.f, 0.f};
-    int kh[4], kw[4];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-        const int k0 = 8 * rg + 4 * g;
-        kh[rg] = k0 / Wp;
-        kw[rg] = k0 % Wp;
-    }
-    const int adv_h = 32 / Wp, adv_w = 32 % Wp;
     int kh0 = 0, phase = 0;
 
     for (int j = 0; j < ntile; ++j) {
@@ -340,29 +366,36 @@ __global__ __launch_bounds__(NT) void bwd_dq_kernel(const bf16* __restrict__ qkv
         const unsigned char* vimg = kimg + IMG;
         const int kh0n = (32 * (j + 1)) / Wp;
         if (valid) {
-            const bf16* ep = etab + (size_t)phase * 1024 + (size_t)g * 256 + (lane & 31) * 8;
+            const unsigned char* ep = etab + phase * 2048 + g * 512 + (lane & 31) * 16;
             const bf16x8 ef0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ep));
-            const bf16x8 ef1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ep + 512));
+            const bf16x8 ef1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(ep + 1024));
+            const uint4 rt = *reinterpret_cast<const uint4*>(rtab + (phase * 2 + g) * 4);
+            const uint32_t rts[4] = {rt.x, rt.y, rt.z, rt.w};
+            const unsigned char* tht = thb + kh0 * 2;
             f32x16 sacc, dpacc;
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const float4 bw = *reinterpret_cast<const float4*>(tw + kw[rg]);
+                const float4 bw = *reinterpret_cast<const float4*>(twb + (rts[rg] & 0xffffu));
                 sacc[rg * 4 + 0] = bw.x; sacc[rg * 4 + 1] = bw.y; sacc[rg * 4 + 2] = bw.z; sacc[rg * 4 + 3] = bw.w;
             }
+            sacc = mfma(rowfrag(kimg, la, 0), qf[0], sacc);
+            dpacc = mfma(rowfrag(vimg, la, 0), dof[0], ndl);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dpacc[r] = ndlt;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 1; s < 4; ++s) {
                 sacc = mfma(rowfrag(kimg, la, s), qf[s], sacc);
                 dpacc = mfma(rowfrag(vimg, la, s), dof[s], dpacc);
             }
             float ds[16];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const float bhx = (float)th[kh[rg]] - lse2;
+                const float bhx = (float)*reinterpret_cast<const bf16*>(tht + (rts[rg] >> 16)) - lse2;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    ds[rg * 4 + e] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + e], sl, bhx)) * dpacc[rg * 4 + e];
+                for (int e = 0; e < 4; ++e) ds[rg * 4 + e] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + e], sl, bhx));
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 t = f32x2{ds[r], ds[r + 1]} * f32x2{dpacc[r], dpacc[r + 1]};
+                ds[r] = t[0]; ds[r + 1] = t[1];
             }
             const bf16x8 dsf0 = packfrag(ds), dsf1 = packfrag(ds + 8);
 #pragma unroll
@@ -383,12 +416,6 @@ __global__ __launch_bounds__(NT) void bwd_dq_kernel(const bf16* __restrict__ qkv
                 if (dlt == 1) { wh[0] = wh[1]; wh[1] = wh[2]; wh[2] = wh[3]; wh[3] = 0.f; }
                 else if (dlt == 2) { wh[0] = wh[2]; wh[1] = wh[3]; wh[2] = 0.f; wh[3] = 0.f; }
                 else if (dlt >= 3) { wh[0] = wh[3]; wh[1] = 0.f; wh[2] = 0.f; wh[3] = 0.f; }
-            }
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                kh[rg] += adv_h;
-                kw[rg] += adv_w;
-                if (kw[rg] >= Wp) { kw[rg] -= Wp; kh[rg] += 1; }
             }
         }
         kh0 = kh0n;
@@ -440,8 +467,9 @@ __global__ __launch_bounds__(NT) void bwd_dq_kernel(const bf16* __restrict__ qkv
 }
 
 // =============================================================================================== backward: dK, dV
-constexpr int AH_LD = 80, AW_LD = 144;     // LDS row strides (bytes) of the transposed kh (bf16) / kw (f32) tables
-__global__ __launch_bounds__(NT) void bwd_dkv_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ dout,
+constexpr int AH_LD = 144, AW_LD = 144;    // LDS row strides (bytes) of the transposed kh / kw tables (32 f32 + pad)
+template <int MINW>
+__global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ dout,
                                                       size_t lddo, const unsigned char* __restrict__ aux, bf16* __restrict__ dqkv,
                                                       int L, int H, int Hp, int Wp, float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -454,7 +482,7 @@ __global__ __launch_bounds__(NT) void bwd_dkv_kernel(const bf16* __restrict__ qk
     const int key = kt * 32 + (lane & 31);
     const int khl = key / Wp, kwl = key % Wp;
     const int stage_bytes = STAGE_QK + Hp * AH_LD + Wp * AW_LD + 128;
-    const int n_h = Hp * 4, n_w = Wp * 8, n_aux = n_h + n_w + 8;       // 16-byte chunks of the aux tile
+    const int n_h = Hp * 8, n_w = Wp * 8, n_aux = n_h + n_w + 8;       // 16-byte chunks of the aux tile
     const size_t atb = aux_tile_bytes(Hp, Wp);
     const unsigned char* aux_bh = aux + ETAB_BYTES + (size_t)bh * (L / 32) * atb;
     LaneAddr la;
@@ -473,7 +501,7 @@ __global__ __launch_bounds__(NT) void bwd_dkv_kernel(const bf16* __restrict__ qk
     uint4 ra0, ra1, ra2;      // aux tile chunks (named registers: an indexed array would live in scratch)
     const int ntile = L / 32;
     auto aux_store = [&](unsigned char* ah, unsigned char* aw, int c, const uint4& v) {
-        if (c < n_h) *reinterpret_cast<uint4*>(ah + (c >> 2) * AH_LD + (c & 3) * 16) = v;
+        if (c < n_h) *reinterpret_cast<uint4*>(ah + (c >> 3) * AH_LD + (c & 7) * 16) = v;
         else if (c < n_h + n_w) *reinterpret_cast<uint4*>(aw + ((c - n_h) >> 3) * AW_LD + ((c - n_h) & 7) * 16) = v;
         else if (c < n_aux) *reinterpret_cast<uint4*>(aw + Wp * AW_LD + (c - n_h - n_w) * 16) = v;
     };
@@ -528,13 +556,16 @@ __global__ __launch_bounds__(NT) void bwd_dkv_kernel(const bf16* __restrict__ qk
             float p[16], ds[16];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const uint2 b4 = *reinterpret_cast<const uint2*>(ah + (8 * rg + 4 * g) * 2);
-                p[rg * 4 + 0] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 0], sl, bf_lo(b4.x)));
-                p[rg * 4 + 1] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 1], sl, bf_hi(b4.x)));
-                p[rg * 4 + 2] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 2], sl, bf_lo(b4.y)));
-                p[rg * 4 + 3] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 3], sl, bf_hi(b4.y)));
+                const float4 b4 = *reinterpret_cast<const float4*>(ah + (8 * rg + 4 * g) * 4);
+                p[rg * 4 + 0] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 0], sl, b4.x));
+                p[rg * 4 + 1] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 1], sl, b4.y));
+                p[rg * 4 + 2] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 2], sl, b4.z));
+                p[rg * 4 + 3] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 3], sl, b4.w));
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ds[rg * 4 + e] = p[rg * 4 + e] * dpacc[rg * 4 + e];
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 t = f32x2{p[r], p[r + 1]} * f32x2{dpacc[r], dpacc[r + 1]};
+                ds[r] = t[0]; ds[r + 1] = t[1];
             }
             const bf16x8 pf0 = packfrag(p), pf1 = packfrag(p + 8), dsf0 = packfrag(ds), dsf1 = packfrag(ds + 8);
 #pragma unroll
@@ -571,20 +602,28 @@ static int set_smem(const void* kern, bool& done) {
 
 bool attn2_ok(int L, int Hp, int Wp) { return L == Hp * Wp && L % 32 == 0 && Wp % 4 == 0 && Wp >= 12 && Wp <= 28 && Hp % 2 == 0 && Hp >= 2; }
 
+// bf16 row stride of the kh table: an odd number of dwords, so the 32 rows of a wave fall into 32 different banks
+static int th_ld(int Hp) {
+    int s = Hp + 2;
+    if (((s / 2) & 1) == 0) s += 2;
+    return s;
+}
+static size_t qside_smem(int Hp, int Wp) { return 2 * a2::STAGE_QK + (size_t)a2::ROWS * (Wp * 4 + th_ld(Hp) * 2) + 1024; }
+
 int attn2_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t ldo, float* lse, int Bn, int L, int H, int Hp, int Wp,
               float scale, hipStream_t st) {
     using namespace a2;
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
-    const size_t smem = 2 * STAGE_QK + (size_t)ROWS * (Wp * 4 + Hp * 2);
+    const size_t smem = qside_smem(Hp, Wp);
     static bool done = false;
     if (int e = set_smem(reinterpret_cast<const void*>(fwd_kernel), done)) return e;
     PA_LAUNCH(fwd_kernel, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, out, (size_t)ldo, lse, L, H, Hp,
-              Wp, NRP, scale);
+              Wp, NRP, scale, th_ld(Hp), etab_phases(Wp));
     return (int)hipGetLastError();
 }
 
 int64_t attn2_aux_bytes(int Bn, int L, int H, int Hp, int Wp) {
-    return (int64_t)a2::ETAB_BYTES + (int64_t)Bn * H * (L / 32) * ((int64_t)Hp * 64 + (int64_t)Wp * 128 + 128);
+    return (int64_t)a2::ETAB_BYTES + (int64_t)Bn * H * (L / 32) * ((int64_t)(Hp + Wp) * 128 + 128);
 }
 
 int attn2_bwd(const bf16* qkv, int64_t ldq, const bf16* rcat, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse,
@@ -595,21 +634,24 @@ int attn2_bwd(const bf16* qkv, int64_t ldq, const bf16* rcat, const bf16* rcatT,
     PA_LAUNCH(etab_kernel, dim3(nphase), dim3(256), 0, st, reinterpret_cast<bf16*>(aux), Wp, nphase);
     int e = (int)hipGetLastError();
     if (e) return e;
+    static const int minw = [] { const char* v = getenv("PA_ATTN_BWD_WAVES"); return v ? atoi(v) : 2; }();
     {
-        const size_t smem = 2 * STAGE_QK + (size_t)ROWS * (Wp * 4 + Hp * 2);
-        static bool done = false;
-        if ((e = set_smem(reinterpret_cast<const void*>(bwd_dq_kernel), done))) return e;
-        PA_LAUNCH(bwd_dq_kernel, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, rcatT, dout, (size_t)lddo,
-                  lse, delta, dqkv, dG, reinterpret_cast<unsigned char*>(aux), L, H, Hp, Wp, NRP, scale, nphase);
+        const size_t smem = qside_smem(Hp, Wp) + (size_t)nphase * 2048;
+        auto kern = minw == 3 ? bwd_dq_kernel<3> : bwd_dq_kernel<2>;
+        static bool done2 = false, done3 = false;
+        if ((e = set_smem(reinterpret_cast<const void*>(kern), minw == 3 ? done3 : done2))) return e;
+        PA_LAUNCH(kern, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, rcatT, dout, (size_t)lddo,
+                  lse, delta, dqkv, dG, reinterpret_cast<unsigned char*>(aux), L, H, Hp, Wp, NRP, scale, th_ld(Hp), nphase);
         if ((e = (int)hipGetLastError())) return e;
     }
     {
         size_t smem = 2 * (size_t)(STAGE_QK + Hp * AH_LD + Wp * AW_LD + 128);
         if (smem < (size_t)NW * 2 * IMG) smem = (size_t)NW * 2 * IMG;
-        if (Hp * 4 + Wp * 8 + 8 > 3 * NT) return (int)hipErrorInvalidValue;
-        static bool done = false;
-        if ((e = set_smem(reinterpret_cast<const void*>(bwd_dkv_kernel), done))) return e;
-        PA_LAUNCH(bwd_dkv_kernel, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, dout, (size_t)lddo,
+        if (Hp * 8 + Wp * 8 + 8 > 3 * NT) return (int)hipErrorInvalidValue;
+        auto kern = minw == 3 ? bwd_dkv_kernel<3> : bwd_dkv_kernel<2>;
+        static bool done2 = false, done3 = false;
+        if ((e = set_smem(reinterpret_cast<const void*>(kern), minw == 3 ? done3 : done2))) return e;
+        PA_LAUNCH(kern, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, dout, (size_t)lddo,
                   reinterpret_cast<const unsigned char*>(aux), dqkv, L, H, Hp, Wp, scale);
         return (int)hipGetLastError();
     }
