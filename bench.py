@@ -8,7 +8,7 @@ painter_vit_large_patch16_input896x448 (train mode: DropPath active), per-GPU ba
 synthetic inputs already resident in HBM; for N > 1 the gradient all-reduce (RCCL, bucketed, overlapped with backward)
 is inside the step.  Prints ONE JSON line on rank 0 (contract in the task statement):
   value       = N * B * K / t      images/sec, t = max over ranks of the barrier-bracketed wall time of exactly K steps
-  roofline    = the dominant kernel (the bf16 MFMA GEMM engine's weight-gradient instantiation by default) measured
+  roofline    = the dominant kernel (the 256x256 bf16 MFMA GEMM's weight-gradient instantiation by default) measured
                 live with HIP events on the launch stream over the timed region: achieved TFLOP/s = algorithmic
                 FLOPs of those launches / their summed duration; peak = 2500 TFLOP/s dense bf16 MFMA.
                 `model_mfma_frac` = images/s/GPU * 4.034 TFLOP (attention+MLP fwd+bwd) / 2.5 PFLOP/s.
@@ -191,8 +191,16 @@ def main():
         ips = world * args.batch * args.steps / dt
         n, kms, tf = timer.result()
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        kname = ("gemm_kernel<bf16,2,2,OpT,OpT,EpiSlab> (nn.Linear weight gradient, split-K)" if args.roofline_kernel == "wgrad"
-                 else "gemm_kernel<bf16,2,2,OpN,OpN,EpiBiasGelu> (fc1 forward)")
+        kname = ("g256::gemm256_kernel<true,true,Epi4Slab> (nn.Linear weight gradient dW = dY^T.X, split over rows; the largest "
+                 "single kernel of the step)" if args.roofline_kernel == "wgrad"
+                 else "g256::gemm256_kernel<false,false,Epi4BiasGelu> (fc1 forward + erf GELU)")
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC pass (tools_gpu_round.sh), per launch
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(args.roofline_kernel)
+            except Exception:
+                traffic = None
         out = {
             "metric": "images/sec (896x448 pairs) ViT-L fwd+bwd",
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -204,7 +212,7 @@ def main():
                        "mode": "eval" if args.eval else "train (DropPath 0.1)", "parallelism": "dp%d" % world,
                        "grad_allreduce": "RCCL bucketed, overlapped with backward" if world > 1 else "n/a"},
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                         "traffic": None, "kernel": kname, "launches": n, "kernel_ms_total": round(kms, 3)},
+                         "traffic": traffic, "kernel": kname, "launches": n, "kernel_ms_total": round(kms, 3)},
             "model_mfma_frac": round(ips / world * FLOP_BLOCKS_FWD_BWD / (peak * 1e12), 4),
             "model_tflops_per_gpu": round(ips / world * FLOP_MODEL_FWD_BWD / 1e12, 2),
             "loss": round(lossv, 6),
