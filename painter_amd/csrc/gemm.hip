@@ -69,66 +69,81 @@ struct EpiSlab {   // fp32 partial result of split z (wgrad)
     }
 };
 
-// ---- 4-wide epilogues of the 256x256 bf16 kernel (gemm256.h): (row i, column j % 4 == 0, D[i][j..j+3], split)
-DEVI void store4(bf16* p, float4 v) { *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)); }
-DEVI void store4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// ---- 8-wide epilogues of the 256x256 bf16 kernel (gemm256.h): (row i, column j % 8 == 0, D[i][j..j+3], D[i][j+4..j+7], split)
+DEVI void store8(bf16* p, float4 a, float4 b) {
+    *reinterpret_cast<uint4*>(p) = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+}
+DEVI void store8(float* p, float4 a, float4 b) {
+    *reinterpret_cast<float4*>(p) = a;
+    *reinterpret_cast<float4*>(p + 4) = b;
+}
 DEVI float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-DEVI float4 load4(const bf16* p) {
-    const uint2 w = *reinterpret_cast<const uint2*>(p);
-    return make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+DEVI float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+DEVI void load8(const bf16* p, float4& a, float4& b) {
+    const uint4 w = *reinterpret_cast<const uint4*>(p);
+    a = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+    b = make_float4(bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w));
 }
 template <typename OutT> struct Epi4Bias {
     OutT* out; size_t ldo; const float* bias; int M, N;
-    DEVI void operator()(int i, int j, float4 v, int) const {
+    DEVI void operator()(int i, int j, float4 a, float4 b, int) const {
         if (i >= M || j >= N) return;
-        if (bias) { const float4 b = load4(bias + j); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
-        store4(out + (size_t)i * ldo + j, v);
+        if (bias) { a = add4(a, load4(bias + j)); b = add4(b, load4(bias + j + 4)); }
+        store8(out + (size_t)i * ldo + j, a, b);
     }
 };
 struct Epi4BiasGelu {
     bf16* pre; bf16* act; size_t ld; const float* bias; int M, N;
-    DEVI void operator()(int i, int j, float4 v, int) const {
+    DEVI void operator()(int i, int j, float4 a, float4 b, int) const {
         if (i >= M || j >= N) return;
-        const float4 b = load4(bias + j);
-        const uint2 pk = make_uint2(pack_bf16x2(v.x + b.x, v.y + b.y), pack_bf16x2(v.z + b.z, v.w + b.w));
-        if (pre) *reinterpret_cast<uint2*>(pre + (size_t)i * ld + j) = pk;
-        store4(act + (size_t)i * ld + j, make_float4(gelu_f(bf16_lo(pk.x)), gelu_f(bf16_hi(pk.x)), gelu_f(bf16_lo(pk.y)), gelu_f(bf16_hi(pk.y))));
+        a = add4(a, load4(bias + j));
+        b = add4(b, load4(bias + j + 4));
+        const uint4 pk = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
+        if (pre) *reinterpret_cast<uint4*>(pre + (size_t)i * ld + j) = pk;
+        store8(act + (size_t)i * ld + j,
+               make_float4(gelu_f(bf16_lo(pk.x)), gelu_f(bf16_hi(pk.x)), gelu_f(bf16_lo(pk.y)), gelu_f(bf16_hi(pk.y))),
+               make_float4(gelu_f(bf16_lo(pk.z)), gelu_f(bf16_hi(pk.z)), gelu_f(bf16_lo(pk.w)), gelu_f(bf16_hi(pk.w))));
     }
 };
 struct Epi4BiasResid {
     float* out; const float* resid; size_t ld; const float* bias; const float* rowscale; int rps; int M, N;
-    DEVI void operator()(int i, int j, float4 v, int) const {
+    DEVI void operator()(int i, int j, float4 a, float4 b, int) const {
         if (i >= M || j >= N) return;
         const float s = rowscale ? rowscale[i / rps] : 1.f;
-        const float4 b = load4(bias + j), r = load4(resid + (size_t)i * ld + j);
-        store4(out + (size_t)i * ld + j, make_float4(r.x + s * (v.x + b.x), r.y + s * (v.y + b.y), r.z + s * (v.z + b.z), r.w + s * (v.w + b.w)));
+        a = add4(a, load4(bias + j));
+        b = add4(b, load4(bias + j + 4));
+        const float4 ra = load4(resid + (size_t)i * ld + j), rb = load4(resid + (size_t)i * ld + j + 4);
+        store8(out + (size_t)i * ld + j, make_float4(ra.x + s * a.x, ra.y + s * a.y, ra.z + s * a.z, ra.w + s * a.w),
+               make_float4(rb.x + s * b.x, rb.y + s * b.y, rb.z + s * b.z, rb.w + s * b.w));
     }
 };
 struct Epi4DGelu {
     bf16* out; const bf16* pre; size_t ld; int M, N;
-    DEVI void operator()(int i, int j, float4 v, int) const {
+    DEVI void operator()(int i, int j, float4 a, float4 b, int) const {
         if (i >= M || j >= N) return;
-        const float4 p = load4(pre + (size_t)i * ld + j);
-        store4(out + (size_t)i * ld + j, make_float4(v.x * gelu_grad_f(p.x), v.y * gelu_grad_f(p.y), v.z * gelu_grad_f(p.z), v.w * gelu_grad_f(p.w)));
+        float4 pa, pb;
+        load8(pre + (size_t)i * ld + j, pa, pb);
+        store8(out + (size_t)i * ld + j,
+               make_float4(a.x * gelu_grad_f(pa.x), a.y * gelu_grad_f(pa.y), a.z * gelu_grad_f(pa.z), a.w * gelu_grad_f(pa.w)),
+               make_float4(b.x * gelu_grad_f(pb.x), b.y * gelu_grad_f(pb.y), b.z * gelu_grad_f(pb.z), b.w * gelu_grad_f(pb.w)));
     }
 };
 struct Epi4PixShuf {
     bf16* out; const float* bias; int Hp, Wp, P, C, M, N;
-    DEVI void operator()(int i, int j, float4 v, int) const {
+    DEVI void operator()(int i, int j, float4 a, float4 b, int) const {
         if (i >= M || j >= N) return;
         const int L = Hp * Wp;
-        const int b = i / L, l = i - b * L, h = l / Wp, w = l - h * Wp;
+        const int bb = i / L, l = i - bb * L, h = l / Wp, w = l - h * Wp;
         const int c = j % C, pq = j / C, q = pq % P, p = pq / P;
-        const size_t y = (size_t)b * Hp * P + h * P + p, x = (size_t)w * P + q;
-        const float4 bb = load4(bias + j);
-        store4(out + (y * (size_t)(Wp * P) + x) * C + c, make_float4(v.x + bb.x, v.y + bb.y, v.z + bb.z, v.w + bb.w));
+        const size_t y = (size_t)bb * Hp * P + h * P + p, x = (size_t)w * P + q;
+        store8(out + (y * (size_t)(Wp * P) + x) * C + c, add4(a, load4(bias + j)), add4(b, load4(bias + j + 4)));
     }
 };
 struct Epi4Slab {
     float* out; size_t ldo; size_t slab; int M, N;
-    DEVI void operator()(int i, int j, float4 v, int split) const {
+    DEVI void operator()(int i, int j, float4 a, float4 b, int split) const {
         if (i >= M || j >= N) return;
-        store4(out + (size_t)split * slab + (size_t)i * ldo + j, v);
+        store8(out + (size_t)split * slab + (size_t)i * ldo + j, a, b);
     }
 };
 
@@ -227,7 +242,7 @@ static int linear_fwd_t(int epi, const T* x, int64_t ldx, const T* w, const floa
                         int64_t ldo, const float* resid, const float* rowscale, int rps, int M, int N, int K,
                         hipStream_t st) {
     if constexpr (std::is_same<T, bf16>::value) {
-        if (g256::ok(M, N, K, false, false, ldx, K) && N % 4 == 0) {
+        if (g256::ok(M, N, K, false, false, ldx, K)) {
             switch (epi) {
             case PA_EPI_BIAS:
                 return g256::launch<false, false>(x, ldx, w, K, Epi4Bias<bf16>{(bf16*)out, (size_t)ldo, bias, M, N}, M, N, K, 1, st);
@@ -269,7 +284,7 @@ static int linear_pixshuf_t(const T* x, int64_t ldx, const T* w, const float* bi
                             int P, int C, int K, hipStream_t st) {
     const int M = Bn * Hp * Wp, N = P * P * C;
     if constexpr (std::is_same<T, bf16>::value) {
-        if (g256::ok(M, N, K, false, false, ldx, K) && C % 4 == 0)
+        if (g256::ok(M, N, K, false, false, ldx, K) && C % 8 == 0)
             return g256::launch<false, false>(x, ldx, w, K, Epi4PixShuf{out, bias, Hp, Wp, P, C, M, N}, M, N, K, 1, st);
     }
     OpN<T> A{x, (size_t)ldx, M, 0};
@@ -289,7 +304,7 @@ template <typename T>
 static int linear_dgrad_t(const T* dy, int64_t lddy, const T* w, const T* pre, T* dx, int64_t lddx, int M, int N, int K,
                           hipStream_t st) {
     if constexpr (std::is_same<T, bf16>::value) {
-        if (g256::ok(M, K, N, false, true, lddy, K) && K % 4 == 0) {
+        if (g256::ok(M, K, N, false, true, lddy, K)) {
             if (pre) return g256::launch<false, true>(dy, lddy, w, K, Epi4DGelu{dx, pre, (size_t)lddx, M, K}, M, K, N, 1, st);
             return g256::launch<false, true>(dy, lddy, w, K, Epi4Bias<bf16>{dx, (size_t)lddx, nullptr, M, K}, M, K, N, 1, st);
         }

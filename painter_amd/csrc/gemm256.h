@@ -110,7 +110,8 @@ template <> struct Frag4<true> {
     }
 };
 
-// Epilogue contract: epi(i, j, v) with j a multiple of 4 and v = D[i][j..j+3]; the functor bounds-checks.
+// Epilogue contract: epi(i, j, lo, hi, split) with j a multiple of 8, lo = D[i][j..j+3], hi = D[i][j+4..j+7]; the functor
+// bounds-checks (N % 8 == 0 is required by ok()).
 template <bool AMM, bool BMM, class Epi>
 __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag, uint32_t lda, const bf16* __restrict__ Bg,
                                                       uint32_t ldb, Epi epi, int M, int N, int ktiles, int ktiles_per_split,
@@ -271,19 +272,33 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
     if (wr == 0) bar();
     wait_vm<0>();          // the clamped tail DMAs must have landed before this workgroup's LDS is handed on
 
-    // ---- epilogue: lane owns row i, 4-column runs
-    const int lr = lane & 31, g = lane >> 5;
+    // ---- epilogue.  A lane owns one output row of each 32x32 block; storing from there would touch 32 cache lines per
+    // store instruction (measured: the store tail cost ~1/3 of a K=1024 tile).  Instead every wave passes its tile, one
+    // 32 x 64 block at a time, through a private LDS scratch ([32][68] floats, padded: conflict-free ds_write_b128) and
+    // re-reads it 8 columns per lane, 8 lanes per row, so the fused epilogue stores whole 128/256-byte row segments.
+    bar();                 // every wave's DMAs have landed and nobody reads the staging units any more
+    {
+        float* stg = reinterpret_cast<float*>(smem + wv * 8704);
+        const int lr = lane & 31, g = lane >> 5, rrow = lane >> 3, c0 = (lane & 7) * 8;
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        const int i = i0 + wr * 128 + (mb >> 1) * 64 + (mb & 1) * 32 + lr;
+        for (int mb = 0; mb < 4; ++mb) {
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = j0 + wc * 64 + nb * 32 + q * 8 + g * 4;
-                const f32x16& c = acc[mb][nb];
-                epi(i, j, make_float4(c[q * 4 + 0], c[q * 4 + 1], c[q * 4 + 2], c[q * 4 + 3]), split);
+                for (int q = 0; q < 4; ++q) {
+                    const f32x16& c = acc[mb][nb];
+                    *reinterpret_cast<float4*>(stg + lr * 68 + nb * 32 + q * 8 + g * 4) =
+                        make_float4(c[q * 4 + 0], c[q * 4 + 1], c[q * 4 + 2], c[q * 4 + 3]);
+                }
+            const int ib = i0 + wr * 128 + (mb >> 1) * 64 + (mb & 1) * 32;
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                const int r = st * 8 + rrow;
+                const float4 lo = *reinterpret_cast<const float4*>(stg + r * 68 + c0);
+                const float4 hi = *reinterpret_cast<const float4*>(stg + r * 68 + c0 + 4);
+                epi(ib + r, j0 + wc * 64 + c0, lo, hi, split);
             }
+        }
     }
 }
 
@@ -311,7 +326,7 @@ static int launch(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi,
 }
 // shapes the kernel accepts; everything else stays on the generic engine (gemm_engine.h)
 static inline bool ok(int M, int N, int K, bool amm, bool bmm, size_t lda, size_t ldb) {
-    if (K % (2 * BK) || M < 8 || N < 8) return false;
+    if (K % (2 * BK) || M < 8 || N < 8 || N % 8) return false;
     if (amm && (M % 8)) return false;
     if (bmm && (N % 8)) return false;
     if ((lda % 8) || (ldb % 8)) return false;
