@@ -99,6 +99,31 @@ DEVI float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
+// bf16-build variants: erf by Abramowitz-Stegun 7.1.26 (|abs err| < 1.5e-7, far below bf16 resolution) -- two
+// transcendentals (rcp, exp2) instead of libm's branchy erff; exp(-x^2/2) is shared between the cdf and the pdf.
+DEVI void gelu_parts(float x, float& cdf, float& pdf_unnorm) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);          // exp(-x^2 / 2)
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float half_erfc = 0.5f * p * t * e;                                       // 0.5 * erfc(|x| / sqrt 2)
+    cdf = x >= 0.f ? 1.0f - half_erfc : half_erfc;
+    pdf_unnorm = e;
+}
+DEVI float gelu_fast(float x) {
+    float c, e;
+    gelu_parts(x, c, e);
+    return x * c;
+}
+DEVI float gelu_grad_fast(float x) {
+    float c, e;
+    gelu_parts(x, c, e);
+    return fmaf(x * 0.39894228040143268f, e, c);
+}
+
 // 4x4 transpose of a register block: in[i] = 4 consecutive elements (along r) of contraction row i;
 // out[j] = the 4 contraction values of element r+j.
 DEVI void transpose4x4(const uint4 (&in)[4], uint4 (&out)[4]) {   // float

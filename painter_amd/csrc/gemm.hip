@@ -101,8 +101,8 @@ struct Epi4BiasGelu {
         const uint4 pk = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
         if (pre) *reinterpret_cast<uint4*>(pre + (size_t)i * ld + j) = pk;
         store8(act + (size_t)i * ld + j,
-               make_float4(gelu_f(bf16_lo(pk.x)), gelu_f(bf16_hi(pk.x)), gelu_f(bf16_lo(pk.y)), gelu_f(bf16_hi(pk.y))),
-               make_float4(gelu_f(bf16_lo(pk.z)), gelu_f(bf16_hi(pk.z)), gelu_f(bf16_lo(pk.w)), gelu_f(bf16_hi(pk.w))));
+               make_float4(gelu_fast(bf16_lo(pk.x)), gelu_fast(bf16_hi(pk.x)), gelu_fast(bf16_lo(pk.y)), gelu_fast(bf16_hi(pk.y))),
+               make_float4(gelu_fast(bf16_lo(pk.z)), gelu_fast(bf16_hi(pk.z)), gelu_fast(bf16_lo(pk.w)), gelu_fast(bf16_hi(pk.w))));
     }
 };
 struct Epi4BiasResid {
@@ -124,8 +124,8 @@ struct Epi4DGelu {
         float4 pa, pb;
         load8(pre + (size_t)i * ld + j, pa, pb);
         store8(out + (size_t)i * ld + j,
-               make_float4(a.x * gelu_grad_f(pa.x), a.y * gelu_grad_f(pa.y), a.z * gelu_grad_f(pa.z), a.w * gelu_grad_f(pa.w)),
-               make_float4(b.x * gelu_grad_f(pb.x), b.y * gelu_grad_f(pb.y), b.z * gelu_grad_f(pb.z), b.w * gelu_grad_f(pb.w)));
+               make_float4(a.x * gelu_grad_fast(pa.x), a.y * gelu_grad_fast(pa.y), a.z * gelu_grad_fast(pa.z), a.w * gelu_grad_fast(pa.w)),
+               make_float4(b.x * gelu_grad_fast(pb.x), b.y * gelu_grad_fast(pb.y), b.z * gelu_grad_fast(pb.z), b.w * gelu_grad_fast(pb.w)));
     }
 };
 struct Epi4PixShuf {
@@ -194,39 +194,49 @@ extern "C" int pa_slab_reduce(const float* in, float* out, int64_t n, int nz, in
     LAUNCH_CHECK();
 }
 
-// column sums of a [M, N] T matrix (bias gradients): stage 1 partial[chunk][N], stage 2 slab reduce
-template <typename T> __global__ void colsum_kernel(const T* x, size_t ld, int M, int N, int rows_per_chunk, float* part) {
-    // block: 64 column-lanes x 4 row-lanes, each column-lane owns 4 consecutive columns
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c0 = (blockIdx.x * 64 + cl) * 4;
+// column sums of a [M, N] T matrix (bias gradients): stage 1 partial[chunk][N], stage 2 slab reduce (fixed order)
+// block = 32 column-lanes (8 consecutive columns each, one 16-byte load for bf16) x 8 row-lanes; 128 rows per block
+template <typename T> __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, size_t ld, int M, int N, int rows_per_chunk, float* __restrict__ part) {
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = (blockIdx.x * 32 + cl) * 8;
     const int r0 = blockIdx.y * rows_per_chunk, r1 = min(M, r0 + rows_per_chunk);
-    float s[4] = {0, 0, 0, 0};
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (c0 < N) {
-        for (int r = r0 + rl; r < r1; r += 4) {
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += 8) {
             const T* p = x + (size_t)r * ld + c0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s[e] += to_f(p[e]);
+            if constexpr (sizeof(T) == 2) {
+                const uint4 w = *reinterpret_cast<const uint4*>(p);
+                s[0] += bf16_lo(w.x); s[1] += bf16_hi(w.x); s[2] += bf16_lo(w.y); s[3] += bf16_hi(w.y);
+                s[4] += bf16_lo(w.z); s[5] += bf16_hi(w.z); s[6] += bf16_lo(w.w); s[7] += bf16_hi(w.w);
+            } else {
+                const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+                s[0] += a.x; s[1] += a.y; s[2] += a.z; s[3] += a.w; s[4] += b.x; s[5] += b.y; s[6] += b.z; s[7] += b.w;
+            }
         }
     }
-    __shared__ float red[4][256];
+    __shared__ float red[8][32 * 8 + 8];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) red[rl][cl * 4 + e] = s[e];
+    for (int e = 0; e < 8; ++e) red[rl][cl * 8 + e] = s[e];
     __syncthreads();
-    if (rl == 0 && c0 < N) {
+    const int c = threadIdx.x;             // 256 columns of this block
+    if (blockIdx.x * 256 + c < N) {
+        float t = 0.f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            part[(size_t)blockIdx.y * N + c0 + e] = red[0][cl * 4 + e] + red[1][cl * 4 + e] + red[2][cl * 4 + e] + red[3][cl * 4 + e];
+        for (int k = 0; k < 8; ++k) t += red[k][c];
+        part[(size_t)blockIdx.y * N + blockIdx.x * 256 + c] = t;
     }
 }
+static int colsum_rows_per_chunk(int M) { return M >= 4096 ? 128 : 32; }
 extern "C" int64_t pa_colsum_workspace_bytes(int M, int N) {
-    const int chunks = (M + 255) / 256;
+    const int rpc = colsum_rows_per_chunk(M), chunks = (M + rpc - 1) / rpc;
     return (int64_t)chunks * N * sizeof(float);
 }
 extern "C" int pa_colsum(int dtype, const void* x, int64_t ld, int M, int N, float* out, void* workspace, hipStream_t st) {
-    if (N % 4) return (int)hipErrorInvalidValue;
-    const int rpc = 256, chunks = (M + rpc - 1) / rpc;
+    if (N % 8 || ld % 8) return (int)hipErrorInvalidValue;
+    const int rpc = colsum_rows_per_chunk(M), chunks = (M + rpc - 1) / rpc;
     float* part = reinterpret_cast<float*>(workspace);
-    dim3 grid((N / 4 + 63) / 64, chunks);
+    dim3 grid((N + 255) / 256, chunks);
     if (dtype == PA_BF16)
         PA_LAUNCH(colsum_kernel<bf16>, grid, dim3(256), 0, st, (const bf16*)x, (size_t)ld, M, N, rpc, part);
     else

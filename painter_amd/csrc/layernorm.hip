@@ -158,7 +158,7 @@ extern "C" int pa_layernorm_fwd(int dtype, const float* x, int64_t ldx, const fl
 
 static int ln_bwd_blocks(int R) {
     int b = (R + 3) / 4;
-    return b > 512 ? 512 : b;
+    return b > 1024 ? 1024 : b;      // 4 waves per SIMD resident on 256 CUs
 }
 extern "C" int64_t pa_layernorm_bwd_workspace_bytes(int R, int D) { return (int64_t)ln_bwd_blocks(R) * 2 * D * sizeof(float); }
 
