@@ -37,6 +37,9 @@ enum {
 };
 
 int pa_abi_version(void);
+/* diagnostics only (tools/): which = 0 start-up stagger of alternate workgroup rows of the 256x256 GEMM in shader cycles,
+ * 1 drop that kernel's epilogue stores.  Never set by the product path. */
+int pa_debug_set(int which, int value);
 
 /* ---- nn.Linear: y = x W^T + b.  models_painter.py:76 (qkv), :87 (proj), timm Mlp fc1/fc2 (:201,:230) ---- */
 int pa_linear_fwd(int dtype, int epilogue, const void* x /*T [M,K]*/, int64_t ldx, const void* w /*T [N,K]*/,

@@ -1,0 +1,269 @@
+// bf16 3x3 convolution kernels for the decoder head (64 -> 64 channels, NHWC, pad 1), written for gfx950:
+//   conv3x3_tile_kernel   out[px][co] = sum_{tap,ci} W[co][tap][ci] . X[px + off(tap)][ci]   (forward tail and data gradient)
+//   conv3x3_wgrad_kernel  dW[co][ci][tap] = sum_px dY[px][co] . X[px + off(tap)][ci]
+// Replaces the im2col gather operands of the generic engine for Painter/models_painter.py:328-333,:430:
+// the gather re-read every input pixel 9 times from L2 in 16-byte pieces; here a workgroup stages one halo tile of the image in
+// LDS once ([pixel][64 ch] = 128-byte rows, 16-byte chunk index XOR-swizzled with a bijection of pixel-column bits 1..3 so that
+// both ds_read_b128 pixel fragments and the transposing ds_read_b64_tr_b16 are bank-conflict free at every tap shift) and
+// every tap is an immediate-offset LDS read of it.
+//   forward / dgrad: workgroup = 4 waves = 4 image rows x 64 pixels, wave = one row (2 segments of 32 pixels) x 64 output
+//     channels; the 9 taps' weights stream through an 8 KB double buffer; 144 MFMA 32x32x16 per wave; 2 workgroups per CU.
+//     MFMA orientation A = weights (i = output channel), B = pixels (j): a lane owns one pixel and 32 of its channels, which is
+//     what the fused LayerNorm2D / GELU / 1x1-conv epilogue wants.
+//   wgrad: persistent workgroups (2 per CU), tile = 2 rows x 64 pixels; wave = (output-channel half, input-channel half), 9 tap
+//     accumulators; the contraction runs over pixels, so both operands are read with the transposing LDS read; the next
+//     tile's global loads are in flight under the current tile's 72 MFMAs; per-workgroup fp32 slabs, reduced in fixed order.
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+namespace c64 {
+
+constexpr int TW = 64;                  // tile width in pixels (both kernels)
+constexpr int HS = 80;                  // LDS pixels per halo row (>= TW + 2, multiple of 16 so the swizzle depends on the column only)
+constexpr int FTH = 4;                  // forward tile height
+constexpr int F_XB = (FTH + 2) * HS * 128, F_WB = 8192, F_LDS = F_XB + 2 * F_WB;
+constexpr int WTH = 2;                  // wgrad tile height
+constexpr int W_XB = (WTH + 2) * HS * 128, W_YB = WTH * TW * 128, W_LDS = W_XB + W_YB;
+constexpr int W_SLAB = 64 * 64 * 9;     // floats per workgroup slab
+
+template <int V> using IC = std::integral_constant<int, V>;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+DEVI int vsw(int r) { return (((r >> 1) & 1) << 2) | (((r >> 2) & 1) << 1) | ((r >> 3) & 1); }
+DEVI int xbyte(int pix, int chunk) { return pix * 128 + ((chunk ^ vsw(pix)) << 4); }
+DEVI f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+DEVI bf16x8 ld_frag(const unsigned char* p) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p)); }
+// transposed fragment: 8 contraction values (pixels 4g + (t & 3) + 8 (t >> 2) of the 16-pixel step) for row (lane & 31)
+DEVI bf16x8 tr_frag(const unsigned char* lo, const unsigned char* hi) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)lo);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)hi);
+    const u32x2 l = __builtin_bit_cast(u32x2, a), h = __builtin_bit_cast(u32x2, b);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(l, h, 0, 1, 2, 3));
+}
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad
+// x: NHWC [B, Hi, Wi, 64] bf16; w: [64 out][9 taps][64 in] bf16; Hi % 4 == 0, Wi % 64 == 0.
+// Epi(acc[2][2], 0, first pixel (linear index) of the wave's 64-pixel run, lane, 0): acc[bi][bj][r] = out channel bi*32 + acc_row(r),
+// pixel bj*32 + (lane & 31).
+template <class Epi>
+__global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w, Epi epi, int Hi, int Wi) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, lr = lane & 31;
+    const int ntx = Wi / TW, nty = Hi / FTH;
+    int t = blockIdx.x;
+    const int bx = t % ntx;
+    t /= ntx;
+    const int by = t % nty, b = t / nty;
+    const int x0 = bx * TW, y0 = by * FTH;
+    const bf16* img = x + (size_t)b * Hi * Wi * 64;
+
+    constexpr int HC = TW + 2, NCH = (FTH + 2) * HC * 8, NLD = (NCH + 255) / 256;
+    uint4 xr[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + 256 * i;
+        xr[i] = zero4();
+        if (idx < NCH) {
+            const int pix = idx >> 3, ch = idx & 7, r = pix / HC, c = pix - r * HC;
+            const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+            if (gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) xr[i] = *reinterpret_cast<const uint4*>(img + ((size_t)gy * Wi + gx) * 64 + ch * 8);
+        }
+    }
+    uint4 wr0, wr1;
+    const int wco0 = tid >> 3, wch = tid & 7;       // weight chunk of this thread: rows wco0 and wco0 + 32
+    auto load_w = [&](int tap) {
+        wr0 = *reinterpret_cast<const uint4*>(w + ((size_t)wco0 * 9 + tap) * 64 + wch * 8);
+        wr1 = *reinterpret_cast<const uint4*>(w + ((size_t)(wco0 + 32) * 9 + tap) * 64 + wch * 8);
+    };
+    auto store_w = [&](int buf) {
+        unsigned char* d = smem + F_XB + buf * F_WB + wco0 * 128 + ((wch ^ vsw(wco0)) << 4);
+        *reinterpret_cast<uint4*>(d) = wr0;
+        *reinterpret_cast<uint4*>(d + 4096) = wr1;
+    };
+    load_w(0);
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + 256 * i;
+        if (idx < NCH) {
+            const int pix = idx >> 3, ch = idx & 7, r = pix / HC, c = pix - r * HC;
+            *reinterpret_cast<uint4*>(smem + xbyte(r * HS + c, ch)) = xr[i];
+        }
+    }
+    store_w(0);
+    __syncthreads();
+
+    // fragment addresses: weights row (lane & 31) [+32 rows = +4096]; pixels: halo row `wave` (+ (dy+1) rows by immediate),
+    // halo column dxi + (lane & 31) (+32 by immediate), chunk 2 s + g
+    int wa[4], xa[3][4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        wa[s] = F_XB + lr * 128 + (((2 * s + g) ^ vsw(lr)) << 4);
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) xa[dxi][s] = xbyte(wave * HS + dxi + lr, 2 * s + g);
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    auto do_tap = [&](auto tap_c) {
+        constexpr int tap = decltype(tap_c)::value, dyi = tap / 3, dxi = tap % 3;
+        if constexpr (tap + 1 < 9) load_w(tap + 1);
+        const unsigned char* wimg = smem + (tap & 1) * F_WB;
+        const unsigned char* ximg = smem + dyi * HS * 128;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 a0 = ld_frag(wimg + wa[s]), a1 = ld_frag(wimg + wa[s] + 4096);
+            const bf16x8 b0 = ld_frag(ximg + xa[dxi][s]), b1 = ld_frag(ximg + xa[dxi][s] + 32 * 128);
+            acc[0][0] = mfma(a0, b0, acc[0][0]);
+            acc[0][1] = mfma(a0, b1, acc[0][1]);
+            acc[1][0] = mfma(a1, b0, acc[1][0]);
+            acc[1][1] = mfma(a1, b1, acc[1][1]);
+        }
+        if constexpr (tap + 1 < 9) store_w((tap + 1) & 1);
+        __syncthreads();
+    };
+    do_tap(IC<0>{}); do_tap(IC<1>{}); do_tap(IC<2>{}); do_tap(IC<3>{}); do_tap(IC<4>{});
+    do_tap(IC<5>{}); do_tap(IC<6>{}); do_tap(IC<7>{}); do_tap(IC<8>{});
+    epi(acc, 0, (int)(((size_t)b * Hi + y0 + wave) * Wi + x0), lane, 0);
+}
+
+template <class Epi> static int launch_tile(const bf16* x, const bf16* w, Epi epi, int Bn, int Hi, int Wi, hipStream_t st) {
+    auto kern = conv3x3_tile_kernel<Epi>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, F_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    PA_LAUNCH(kern, dim3(Bn * (Hi / FTH) * (Wi / TW)), dim3(256), F_LDS, st, x, w, epi, Hi, Wi);
+    return (int)hipGetLastError();
+}
+static inline bool ok(int Bn, int Hi, int Wi) {
+    return Hi % FTH == 0 && Hi % WTH == 0 && Wi % TW == 0 && (size_t)Bn * Hi * Wi < (1ull << 31);
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+static inline int wgrad_groups(int ntiles) { return ntiles < 512 ? ntiles : 512; }
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, float* __restrict__ slab,
+                                                               int Hi, int Wi, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
+    const int coh = wave & 1, cih = wave >> 1;
+    const int ntx = Wi / TW, nty = Hi / WTH;
+    constexpr int HC = TW + 2, NXC = (WTH + 2) * HC * 8, NXL = (NXC + 255) / 256, NYL = WTH * TW * 8 / 256;
+
+    uint4 xr[NXL], yr[NYL];
+    auto load_tile = [&](int tile) {
+        int t = tile;
+        const int bx = t % ntx;
+        t /= ntx;
+        const int by = t % nty, b = t / nty;
+        const int x0 = bx * TW, y0 = by * WTH;
+        const bf16* img = x + (size_t)b * Hi * Wi * 64;
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int idx = tid + 256 * i;
+            xr[i] = zero4();
+            if (idx < NXC) {
+                const int pix = idx >> 3, ch = idx & 7, r = pix / HC, c = pix - r * HC;
+                const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+                if (gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) xr[i] = *reinterpret_cast<const uint4*>(img + ((size_t)gy * Wi + gx) * 64 + ch * 8);
+            }
+        }
+        const bf16* dimg = dy + (((size_t)b * Hi + y0) * Wi + x0) * 64;
+#pragma unroll
+        for (int i = 0; i < NYL; ++i) {
+            const int idx = tid + 256 * i, pix = idx >> 3, ch = idx & 7, r = pix >> 6, c = pix & 63;
+            yr[i] = *reinterpret_cast<const uint4*>(dimg + ((size_t)r * Wi + c) * 64 + ch * 8);
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
+            const int idx = tid + 256 * i;
+            if (idx < NXC) {
+                const int pix = idx >> 3, ch = idx & 7, r = pix / HC, c = pix - r * HC;
+                *reinterpret_cast<uint4*>(smem + xbyte(r * HS + c, ch)) = xr[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NYL; ++i) {
+            const int idx = tid + 256 * i, pix = idx >> 3, ch = idx & 7;
+            *reinterpret_cast<uint4*>(smem + W_XB + xbyte(pix, ch)) = yr[i];
+        }
+    };
+
+    // transposed-fragment addresses for 16-pixel step 0 of a row (steps / rows / tap rows are immediates)
+    const int i16 = lane & 15, half = (lane >> 4) & 1;
+    int ya[2], xa[3][2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+        const int p = 4 * g + (i16 >> 2) + 8 * hi;
+        const int sub = 2 * half + ((i16 & 3) >> 1);
+        ya[hi] = W_XB + p * 128 + (((4 * coh + sub) ^ vsw(p)) << 4) + (i16 & 1) * 8;
+#pragma unroll
+        for (int dxi = 0; dxi < 3; ++dxi) {
+            const int c = dxi + p;
+            xa[dxi][hi] = c * 128 + (((4 * cih + sub) ^ vsw(c)) << 4) + (i16 & 1) * 8;
+        }
+    }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    auto step = [&](auto rr_c, auto m_c) {
+        constexpr int rr = decltype(rr_c)::value, m = decltype(m_c)::value;
+        constexpr int yo = (rr * TW + 16 * m) * 128;
+        const bf16x8 a = tr_frag(smem + ya[0] + yo, smem + ya[1] + yo);
+        auto one = [&](auto tap_c) {
+            constexpr int tap = decltype(tap_c)::value;
+            constexpr int xo = ((rr + tap / 3) * HS + 16 * m) * 128;
+            const bf16x8 bb = tr_frag(smem + xa[tap % 3][0] + xo, smem + xa[tap % 3][1] + xo);
+            acc[tap] = mfma(a, bb, acc[tap]);
+        };
+        one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{}); one(IC<4>{}); one(IC<5>{}); one(IC<6>{}); one(IC<7>{}); one(IC<8>{});
+    };
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        load_tile(tile);
+        __syncthreads();                       // every wave has finished reading the previous tile
+        store_tile();
+        __syncthreads();
+        step(IC<0>{}, IC<0>{}); step(IC<0>{}, IC<1>{}); step(IC<0>{}, IC<2>{}); step(IC<0>{}, IC<3>{});
+        step(IC<1>{}, IC<0>{}); step(IC<1>{}, IC<1>{}); step(IC<1>{}, IC<2>{}); step(IC<1>{}, IC<3>{});
+    }
+    float* o = slab + (size_t)blockIdx.x * W_SLAB;
+    const int ci = cih * 32 + (lane & 31);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = coh * 32 + acc_row(r, lane);
+            o[((size_t)co * 64 + ci) * 9 + tap] = acc[tap][r];
+        }
+}
+
+static int launch_wgrad(const bf16* dy, const bf16* x, float* slab, int Bn, int Hi, int Wi, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    const int ntiles = Bn * (Hi / WTH) * (Wi / TW);
+    PA_LAUNCH(conv3x3_wgrad_kernel, dim3(wgrad_groups(ntiles)), dim3(256), W_LDS, st, dy, x, slab, Hi, Wi, ntiles);
+    return (int)hipGetLastError();
+}
+
+}   // namespace c64

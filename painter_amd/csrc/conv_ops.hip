@@ -5,6 +5,7 @@
 //     (models_painter.py:328-333, :430; util/vitdet_utils.py:204-209)  
 //   * their weight / data gradients.
 #include "gemm_engine.h"
+#include "conv64.h"
 #include "../../include/painter_hip.h"
 
 // ------------------------------------------------------------------------------- patch embed operands
@@ -174,7 +175,7 @@ template <typename T> struct OpConvT {
 // Fused tail epilogue.  Orientation: A = conv weights (i = cout, all 64 in the wave tile), B = pixels (j), so a
 // lane holds ONE pixel and 32 of its 64 channels (the other 32 live in lane ^ 32): LayerNorm2D and the 1x1 conv
 // are in-lane sums plus one half-wave exchange.
-template <typename T> struct EpiTail {
+template <typename T, bool FAST = false> struct EpiTail {
     const float* b3; const float* gamma; const float* beta; const float* w1; const float* b1;   // w1 [3][64]
     T* y3;           // conv3x3 output + bias, NHWC [pixels][64] (saved for backward; may be NULL)
     float* pred;     // NCHW [B, 3, Hi, Wi]
@@ -223,8 +224,10 @@ template <typename T> struct EpiTail {
                     const float4 ga = *reinterpret_cast<const float4*>(gamma + c0), be = *reinterpret_cast<const float4*>(beta + c0);
                     const float4 wa = *reinterpret_cast<const float4*>(w1 + c0), wb = *reinterpret_cast<const float4*>(w1 + CV_C + c0),
                                  wc = *reinterpret_cast<const float4*>(w1 + 2 * CV_C + c0);
-                    const float a0 = gelu_f((y[o + 0] - mu) * rs * ga.x + be.x), a1 = gelu_f((y[o + 1] - mu) * rs * ga.y + be.y),
-                                a2 = gelu_f((y[o + 2] - mu) * rs * ga.z + be.z), a3 = gelu_f((y[o + 3] - mu) * rs * ga.w + be.w);
+                    const float z0 = (y[o + 0] - mu) * rs * ga.x + be.x, z1 = (y[o + 1] - mu) * rs * ga.y + be.y,
+                                z2 = (y[o + 2] - mu) * rs * ga.z + be.z, z3 = (y[o + 3] - mu) * rs * ga.w + be.w;
+                    const float a0 = FAST ? gelu_fast(z0) : gelu_f(z0), a1 = FAST ? gelu_fast(z1) : gelu_f(z1),
+                                a2 = FAST ? gelu_fast(z2) : gelu_f(z2), a3 = FAST ? gelu_fast(z3) : gelu_f(z3);
                     o0 += (a0 * wa.x + a1 * wa.y) + (a2 * wa.z + a3 * wa.w);
                     o1 += (a0 * wb.x + a1 * wb.y) + (a2 * wb.z + a3 * wb.w);
                     o2 += (a0 * wc.x + a1 * wc.y) + (a2 * wc.z + a3 * wc.w);
@@ -247,6 +250,10 @@ template <typename T>
 static int tail_fwd_t(const T* x, const T* w3r, const float* b3, const float* gamma, const float* beta, const float* w1, const float* b1,
                       T* y3, float* pred, int Bn, int Hi, int Wi, float eps, hipStream_t st) {
     const int N = Bn * Hi * Wi;
+    if constexpr (std::is_same<T, bf16>::value) {
+        if (c64::ok(Bn, Hi, Wi))
+            return c64::launch_tile(x, w3r, EpiTail<bf16, true>{b3, gamma, beta, w1, b1, y3, pred, Hi * Wi, N, eps}, Bn, Hi, Wi, st);
+    }
     OpN<T> A{w3r, (size_t)9 * CV_C, CV_C, 0};
     OpConv<T> B{x, Hi, Wi, N};
     return launch_gemm<T, 1, 4>(A, B, EpiTail<T>{b3, gamma, beta, w1, b1, y3, pred, Hi * Wi, N, eps}, CV_C, N, 9 * CV_C, 1, 1, st);
@@ -293,9 +300,32 @@ template <typename T> struct EpiUnshuf {
         });
     }
 };
+// the same for the tile kernel's orientation (lane = pixel, registers = channels): 8-byte runs of 4 channels
+struct EpiUnshufPx {
+    bf16* out; int Hp, Wp, P;
+    DEVI void operator()(const f32x16 (&acc)[2][2], int, int jb, int lane, int) const {
+        const int Wi = Wp * P, HW = Hp * P * Wi, g = lane >> 5;
+#pragma unroll
+        for (int bj = 0; bj < 2; ++bj) {
+            const int pix = jb + bj * 32 + (lane & 31);
+            const int b = pix / HW, rem = pix % HW, y = rem / Wi, x = rem % Wi;
+            const int h = y / P, p = y % P, w = x / P, q = x % P;
+            bf16* dst = out + (((size_t)b * Hp + h) * Wp + w) * (size_t)(P * P * CV_C) + (size_t)(p * P + q) * CV_C;
+#pragma unroll
+            for (int bi = 0; bi < 2; ++bi)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    *reinterpret_cast<uint2*>(dst + bi * 32 + 8 * rg + 4 * g) =
+                        make_uint2(pack_bf16x2(acc[bi][bj][rg * 4], acc[bi][bj][rg * 4 + 1]), pack_bf16x2(acc[bi][bj][rg * 4 + 2], acc[bi][bj][rg * 4 + 3]));
+        }
+    }
+};
 template <typename T>
 static int conv_dgrad_t(const T* dy3, const T* wf, T* dE, int Bn, int Hp, int Wp, int P, hipStream_t st) {
     const int Hi = Hp * P, Wi = Wp * P, N = Bn * Hi * Wi;
+    if constexpr (std::is_same<T, bf16>::value) {
+        if (c64::ok(Bn, Hi, Wi)) return c64::launch_tile(dy3, wf, EpiUnshufPx{dE, Hp, Wp, P}, Bn, Hi, Wi, st);
+    }
     OpConv<T> A{dy3, Hi, Wi, N};
     OpN<T> B{wf, (size_t)9 * CV_C, CV_C, 0};
     return launch_gemm<T, 4, 1>(A, B, EpiUnshuf<T>{dE, Hp, Wp, P, N}, N, CV_C, 9 * CV_C, 1, 1, st);
@@ -323,11 +353,24 @@ static int conv_wgrad_splits(int npix) {
     return s;
 }
 extern "C" int64_t pa_conv3x3_wgrad_workspace_bytes(int batch, int Hi, int Wi) {
-    return (int64_t)conv_wgrad_splits(batch * Hi * Wi) * CV_C * CV_C * 9 * sizeof(float);
+    int s = conv_wgrad_splits(batch * Hi * Wi);
+    if (c64::ok(batch, Hi, Wi)) {
+        const int groups = c64::wgrad_groups(batch * (Hi / c64::WTH) * (Wi / c64::TW));
+        if (groups > s) s = groups;
+    }
+    return (int64_t)s * CV_C * CV_C * 9 * sizeof(float);
 }
 template <typename T>
 static int conv_wgrad_t(const T* dy3, const T* x, float* dw, float* ws, int Bn, int Hi, int Wi, hipStream_t st) {
     const int N = Bn * Hi * Wi;
+    if constexpr (std::is_same<T, bf16>::value) {
+        if (c64::ok(Bn, Hi, Wi)) {
+            const int groups = c64::wgrad_groups(Bn * (Hi / c64::WTH) * (Wi / c64::TW));
+            int e = c64::launch_wgrad(dy3, x, ws, Bn, Hi, Wi, st);
+            if (e) return e;
+            return pa_slab_reduce(ws, dw, (int64_t)c64::W_SLAB, groups, (int64_t)c64::W_SLAB, 0, st);
+        }
+    }
     OpT<T> A{dy3, (size_t)CV_C, CV_C, 0};
     OpConvT<T> B{x, Hi, Wi, 9 * CV_C};
     const int s = conv_wgrad_splits(N);

@@ -388,3 +388,8 @@ extern "C" int pa_linear_wgrad(int dtype, const void* dy, int64_t lddy, const vo
 }
 
 extern "C" int pa_abi_version(void) { return 1; }
+extern "C" int pa_debug_set(int which, int value) {
+    if (which < 0 || which >= 4) return (int)hipErrorInvalidValue;
+    g256::g_dbg[which] = value;
+    return 0;
+}

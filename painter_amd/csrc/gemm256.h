@@ -25,6 +25,8 @@ namespace g256 {
 
 constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
 constexpr int LDS_BYTES = 131072;
+// diagnostics (pa_debug_set): [0] start-up stagger of every other workgroup row in shader cycles, [1] drop epilogue stores
+inline int g_dbg[4] = {0, 0, 0, 0};
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
@@ -115,9 +117,13 @@ template <> struct Frag4<true> {
 template <bool AMM, bool BMM, class Epi>
 __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag, uint32_t lda, const bf16* __restrict__ Bg,
                                                       uint32_t ldb, Epi epi, int M, int N, int ktiles, int ktiles_per_split,
-                                                      int tiles_n) {
+                                                      int tiles_n, int stagger) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
+    if (stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+        const uint64_t t0 = __builtin_amdgcn_s_memtime();
+        while ((int64_t)(__builtin_amdgcn_s_memtime() - t0) < (int64_t)stagger) __builtin_amdgcn_s_sleep(32);
+    }
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 2, wc = wv & 3;
 
@@ -320,8 +326,9 @@ static int launch(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi,
     const int ktiles = K / BK;
     const int per = per_split(ktiles, nsplit);
     const int splits = (ktiles + per - 1) / per;      // every split gets an even number (>= 2) of tiles
+    if (g_dbg[1]) epi.M = 0;
     PA_LAUNCH(kern, dim3(tiles_m * tiles_n, splits), dim3(NT), LDS_BYTES, st, A, (uint32_t)lda, B, (uint32_t)ldb, epi, M, N,
-              ktiles, per, tiles_n);
+              ktiles, per, tiles_n, g_dbg[0]);
     return (int)hipGetLastError();
 }
 // shapes the kernel accepts; everything else stays on the generic engine (gemm_engine.h)

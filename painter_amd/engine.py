@@ -12,6 +12,8 @@ Data layout in HBM (per rank):
   decoder image            T    NHWC [B, H, W, 64]  pixel shuffle fused into decoder_embed's epilogue
   pred / loss              fp32 NCHW [B,3,H,W], [2]
 """
+import os
+
 import torch
 
 from . import hostmath, ops
@@ -72,6 +74,17 @@ class HotPath:
         self.T = compute_dtype
         self._M = None
         self._wcache = {}
+        self._side = {}
+        # parameter-gradient kernels (dW = dY^T.X, bias column sums) are off the backward's critical path: they go to a second
+        # HIP stream so that the chip fills the CUs the dgrad/LayerNorm kernels of the main stream leave idle (section 6)
+        self.use_side_stream = os.environ.get("PAINTER_AMD_SIDE_STREAM", "1") != "0"
+
+    def side_stream(self, device):
+        s = self._side.get(device)
+        if s is None:
+            s = torch.cuda.Stream(device=device)
+            self._side[device] = s
+        return s
 
     # ------------------------------------------------------------------ constants / casts
     def pos_operator(self, device):
@@ -164,11 +177,41 @@ class HotPath:
     # ------------------------------------------------------------------ backward
     def backward(self, P, S, dloss, sync=None):
         """-> {param name: fp32 grad}.  dloss: 0-d / [1] fp32 device tensor (may carry a GradScaler factor).
-        sync: optional painter_amd.parallel.GradSync; buckets are handed over as soon as they are enqueued."""
+        sync: optional painter_amd.parallel.GradSync; buckets are handed over as soon as they are enqueued.
+
+        Two HIP streams: the data-gradient chain (dgrad GEMMs, attention backward, LayerNorm backward) runs on the caller's
+        stream; every weight/bias gradient of an nn.Linear (wgrad GEMM + slab reduction + column sum) is enqueued on a side
+        stream behind an event, because nothing downstream in the backward consumes it."""
         c, T = self.cfg, self.T
         B, L, D = S.B, c.L, c.D
         dev = S.imgs.device
         G = {}
+        main = torch.cuda.current_stream(dev)
+        side = self.side_stream(dev) if self.use_side_stream else None
+
+        def param_grads(wname, bname, dy, x):
+            """G[wname] = dy^T.x, G[bname] = colsum(dy) -- on the side stream when enabled."""
+            if side is None:
+                G[wname] = ops.linear_wgrad(dy, x)
+                G[bname] = ops.colsum(dy)
+                return
+            side.wait_stream(main)                 # dy (and x) are enqueued on main
+            with torch.cuda.stream(side):
+                G[wname] = ops.linear_wgrad(dy, x)
+                G[bname] = ops.colsum(dy)
+            dy.record_stream(side)                 # the allocator must not hand these out again before the side stream is done
+            x.record_stream(side)
+
+        def ready(names):
+            if sync is None:
+                return
+            if side is None:
+                sync.ready(G, names)
+                return
+            side.wait_stream(main)                 # the bucket's gradients come from both streams
+            with torch.cuda.stream(side):
+                sync.ready(G, names)
+
         dpred = ops.loss_bwd(S.pred, S.tgts, S.valid, S.mask, dloss, S.loss_out, c.P, c.loss_func)
         w1 = P["decoder_pred.3.weight"].reshape(3, c.dec)
         dy3, tg = ops.decoder_tail_bwd_pointwise(dpred, S.y3, P["decoder_pred.1.weight"], P["decoder_pred.1.bias"], w1, 1e-6)
@@ -181,13 +224,11 @@ class HotPath:
         G["decoder_pred.0.bias"] = ops.colsum(dy3.view(npix, c.dec))
         dE = ops.conv3x3_dgrad_unshuffle(dy3, S.wf, B, c.Hp, c.Wp, c.P)
         del dy3
-        G["decoder_embed.weight"] = ops.linear_wgrad(dE, S.concat)
-        G["decoder_embed.bias"] = ops.colsum(dE)
+        param_grads("decoder_embed.weight", "decoder_embed.bias", dE, S.concat)
         dconcat = ops.linear_dgrad(dE, self.w("decoder_embed.weight", P))
         del dE
-        if sync is not None:
-            sync.ready(G, ["decoder_embed.weight", "decoder_embed.bias"])
-            sync.ready(G, [n for n in G if n.startswith("decoder_pred.")])
+        ready(["decoder_embed.weight", "decoder_embed.bias"])
+        ready([n for n in G if n.startswith("decoder_pred.")])
         dnorm = None
         dx = None
         for i in reversed(range(c.depth)):
@@ -206,33 +247,33 @@ class HotPath:
             else:
                 dyT = ops.scale_cast(T, dx, ds_m, L)
             # ---- MLP branch: x2 = x1 + s_m * fc2(gelu(fc1(LN2(x1))))
-            G[pre + "mlp.fc2.weight"] = ops.linear_wgrad(dyT, act)
-            G[pre + "mlp.fc2.bias"] = ops.colsum(dyT)
+            param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dyT, act)
             dpre = ops.linear_dgrad(dyT, self.w(pre + "mlp.fc2.weight", P), pre=hpre)
-            G[pre + "mlp.fc1.weight"] = ops.linear_wgrad(dpre, ln2)
-            G[pre + "mlp.fc1.bias"] = ops.colsum(dpre)
+            param_grads(pre + "mlp.fc1.weight", pre + "mlp.fc1.bias", dpre, ln2)
             dln2 = ops.linear_dgrad(dpre, self.w(pre + "mlp.fc1.weight", P))
             del dpre
-            dx, gb = ops.layernorm_bwd(dln2, x1, mean2, rstd2, P[pre + "norm2.weight"], dres=dx, dx=dx, dxT=dyT,
+            # dyT may still be read by the side stream: the attention branch's dY gets its own buffer
+            dyA = torch.empty_like(dyT) if side is not None else dyT
+            dx, gb = ops.layernorm_bwd(dln2, x1, mean2, rstd2, P[pre + "norm2.weight"], dres=dx, dx=dx, dxT=dyA,
                                        rowscale=ds_a, rows_per_sample=L)
+            del dyT
             G[pre + "norm2.weight"], G[pre + "norm2.bias"] = gb[0], gb[1]
             # ---- attention branch: x1 = x0 + s_a * proj(attn(LN1(x0)))
-            G[pre + "attn.proj.weight"] = ops.linear_wgrad(dyT, ao)
-            G[pre + "attn.proj.bias"] = ops.colsum(dyT)
-            dao = ops.linear_dgrad(dyT, self.w(pre + "attn.proj.weight", P), out=dln2)
+            param_grads(pre + "attn.proj.weight", pre + "attn.proj.bias", dyA, ao)
+            dao = ops.linear_dgrad(dyA, self.w(pre + "attn.proj.weight", P), out=dln2)
+            del dyA
             rcatT = ops.relpos_pack_t(P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], c.Hp, c.Wp, T)
             dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, ao, dao, lse, Bc, L, c.heads, c.Hp, c.Wp, c.scale)
             nh, nw = 2 * c.Hp - 1, 2 * c.Wp - 1
             G[pre + "attn.rel_pos_h"] = drcat[:nh]
             G[pre + "attn.rel_pos_w"] = drcat[nh:nh + nw]
-            G[pre + "attn.qkv.weight"] = ops.linear_wgrad(dqkv, ln1)
-            G[pre + "attn.qkv.bias"] = ops.colsum(dqkv)
+            param_grads(pre + "attn.qkv.weight", pre + "attn.qkv.bias", dqkv, ln1)
             dln1 = ops.linear_dgrad(dqkv, self.w(pre + "attn.qkv.weight", P), out=dao)
             del dqkv
             dx, gb = ops.layernorm_bwd(dln1, x0, mean1, rstd1, P[pre + "norm1.weight"], dres=dx, dx=dx)
             G[pre + "norm1.weight"], G[pre + "norm1.bias"] = gb[0], gb[1]
-            if sync is not None:
-                sync.ready(G, [n for n in G if n.startswith(pre)])
+            del x0, ln1, qkv, ao, x1, ln2, hpre, act
+            ready([n for n in G if n.startswith(pre)])
         G["norm.weight"], G["norm.bias"] = dnorm[0], dnorm[1]
         # ---- token assembly + patch embed
         dpe, sums = ops.tokens_bwd(T, dx, S.mask, B, L, D)
@@ -244,9 +285,11 @@ class HotPath:
         G["segment_token_x"] = ops.colsum(sums[0]).view(1, 1, 1, D)
         G["segment_token_y"] = ops.colsum(sums[1]).view(1, 1, 1, D)
         G["mask_token"] = ops.colsum(sums[2]).view(1, 1, 1, D)
+        ready(["norm.weight", "norm.bias", "patch_embed.proj.weight", "patch_embed.proj.bias", "pos_embed",
+               "segment_token_x", "segment_token_y", "mask_token"])
+        if side is not None:
+            main.wait_stream(side)                 # every gradient is ordered before whatever the caller enqueues next
         if sync is not None:
-            sync.ready(G, ["norm.weight", "norm.bias", "patch_embed.proj.weight", "patch_embed.proj.bias", "pos_embed",
-                           "segment_token_x", "segment_token_y", "mask_token"])
             sync.finish()
         return G
 

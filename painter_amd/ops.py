@@ -24,8 +24,8 @@ def p(t):
 
 
 def workspace(nbytes, device, slot=0):
-    """Grow-only scratch per (device, slot); safe to reuse because every user is stream-ordered."""
-    key = (device, slot)
+    """Grow-only scratch per (device, slot, current stream); safe to reuse because every user on one stream is ordered."""
+    key = (device, slot, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

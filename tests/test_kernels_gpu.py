@@ -256,3 +256,41 @@ def test_determinism_same_input_bit_identical():
     assert torch.equal(a, b)
     c, d = ops.linear_dgrad(dy, w).clone(), ops.linear_dgrad(dy, w).clone()
     assert torch.equal(c, d)
+
+
+@pytest.mark.parametrize("B,Hi,Wi", [(2, 16, 128), (1, 32, 64)])
+def test_conv64_bf16_tile_kernels(B, Hi, Wi):
+    """Dedicated bf16 3x3 conv kernels (csrc/conv64.h; Wi % 64 == 0 takes them): fused decoder tail forward, data gradient with
+    the inverse pixel shuffle, weight gradient -- against torch conv2d on the same bf16-rounded operands
+    (models_painter.py:328-333, :430)."""
+    import torch.nn.functional as F
+    T = torch.bfloat16
+    P, Hp, Wp = 16, Hi // 16, Wi // 16
+    x = gen((B, Hi, Wi, 64), 1, 1.0, T)                       # NHWC
+    w3 = gen((64, 64, 3, 3), 2, 0.05)
+    b3, gamma, beta = gen((64,), 3, 0.1), 1.0 + gen((64,), 4, 0.1), gen((64,), 5, 0.1)
+    w1, b1 = gen((3, 64), 6, 0.1), gen((3,), 7, 0.1)
+    w3r, wf = ops.conv3x3_pack(w3, T)
+    pred, y3 = ops.decoder_tail_fwd(x, w3r, b3, gamma, beta, w1, b1, 1e-6, save_y3=True)
+    xn = x.float().permute(0, 3, 1, 2)
+    w3b = w3.to(T).float()
+    y_ref = F.conv2d(xn, w3b, b3, padding=1)
+    assert relerr(y3.float().permute(0, 3, 1, 2), y_ref) < 1e-2
+    yq = y3.float().permute(0, 3, 1, 2)                         # the kernel normalises the bf16-rounded conv output
+    u = yq.mean(1, keepdim=True)
+    s = (yq - u).pow(2).mean(1, keepdim=True)
+    z = (yq - u) / torch.sqrt(s + 1e-6) * gamma[None, :, None, None] + beta[None, :, None, None]
+    pred_ref = F.conv2d(F.gelu(z), w1[:, :, None, None], b1)
+    assert relerr(pred, pred_ref) < 2e-3
+    # data gradient + inverse pixel shuffle
+    dy = gen((B, Hi, Wi, 64), 8, 1.0, T)
+    dE = ops.conv3x3_dgrad_unshuffle(dy, wf, B, Hp, Wp, P)
+    dx_ref = F.conv_transpose2d(dy.float().permute(0, 3, 1, 2), w3b, padding=1)          # [B,64,Hi,Wi]
+    dx_tok = dx_ref.reshape(B, 64, Hp, P, Wp, P).permute(0, 2, 4, 3, 5, 1).reshape(B * Hp * Wp, P * P * 64)
+    assert relerr(dE.float(), dx_tok) < 1e-2
+    # weight gradient (fp32 accumulate, deterministic)
+    dw = ops.conv3x3_wgrad(dy, x)
+    dyn = dy.float().permute(0, 3, 1, 2)
+    dw_ref = torch.nn.grad.conv2d_weight(xn, (64, 64, 3, 3), dyn, padding=1)
+    assert relerr(dw, dw_ref) < 1e-4
+    assert torch.equal(dw, ops.conv3x3_wgrad(dy, x))
