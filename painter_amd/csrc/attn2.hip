@@ -161,6 +161,7 @@ DEVI void write_rows(const unsigned char* stg, bf16* dst, size_t ld, int lane) {
 
 // =============================================================================================== forward
 // LDS: [K img | V img] x 2 stages (16 KB) | tw f32 [128][Wp] | th bf16 [128][thld] | run table [nphase][2][4] u32
+template <int PF>
 __global__ __launch_bounds__(NT, 2) void fwd_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
                                                   bf16* __restrict__ out, size_t ldo, float* __restrict__ lse, int L, int H, int Hp,
                                                   int Wp, int NRP, float scale, int thld, int nphase) {
@@ -186,12 +187,19 @@ __global__ __launch_bounds__(NT, 2) void fwd_kernel(const bf16* __restrict__ qkv
         for (int s = 0; s < 4; ++s) qf[s] = gfrag(base + (size_t)q * ldq, s, g);
         build_tables(reinterpret_cast<float*>(twb), reinterpret_cast<bf16*>(thb), rcat, NRP, qf, q / Wp, q % Wp, Hp, Wp, 1.f / scale, lane);
     }
-    Stager ks, vs;
+    // K/V tiles are register-staged PF tiles ahead (global -> VGPR at the top of iteration j for tile j + PF, VGPR -> LDS at the
+    // bottom of iteration j for tile j + 1): with PF = 2 a load has a whole iteration of MFMA work to cover its L2 latency.
+    Stager ksA, vsA, ksB, vsB;
     const int ntile = L / 32;
-    ks.load(kbase, ldq, tid);
-    vs.load(vbase, ldq, tid);
-    ks.store(smem, tid);
-    vs.store(smem + IMG, tid);
+    ksA.load(kbase, ldq, tid);
+    vsA.load(vbase, ldq, tid);
+    ksA.store(smem, tid);
+    vsA.store(smem + IMG, tid);
+    if (PF == 2) {
+        const int j1 = min(1, ntile - 1);
+        ksA.load(kbase + (size_t)j1 * 32 * ldq, ldq, tid);
+        vsA.load(vbase + (size_t)j1 * 32 * ldq, ldq, tid);
+    }
     __syncthreads();
 
     f32x16 oacc[2];
@@ -201,10 +209,12 @@ __global__ __launch_bounds__(NT, 2) void fwd_kernel(const bf16* __restrict__ qkv
     const float sl = scale * LOG2E_F;
     int phase = 0;
 
-    for (int j = 0; j < ntile; ++j) {
-        if (j + 1 < ntile) {
-            ks.load(kbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
-            vs.load(vbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
+    auto iter = [&](int j, Stager& kl, Stager& vl, Stager& kst, Stager& vst) {
+        {   // unconditional (clamped to the last tile): a static number of loads in flight lets hipcc emit a counted vmcnt wait
+            // for the set that is stored below instead of draining the loads just issued
+            const int jn = min(j + PF, ntile - 1);
+            kl.load(kbase + (size_t)jn * 32 * ldq, ldq, tid);
+            vl.load(vbase + (size_t)jn * 32 * ldq, ldq, tid);
         }
         const unsigned char* kimg = smem + (j & 1) * STAGE_QK;
         const unsigned char* vimg = kimg + IMG;
@@ -249,10 +259,20 @@ __global__ __launch_bounds__(NT, 2) void fwd_kernel(const bf16* __restrict__ qkv
         }
         phase = phase + 1 == nphase ? 0 : phase + 1;
         if (j + 1 < ntile) {
-            ks.store(smem + ((j + 1) & 1) * STAGE_QK, tid);
-            vs.store(smem + ((j + 1) & 1) * STAGE_QK + IMG, tid);
+            kst.store(smem + ((j + 1) & 1) * STAGE_QK, tid);
+            vst.store(smem + ((j + 1) & 1) * STAGE_QK + IMG, tid);
         }
         __syncthreads();
+    };
+    if constexpr (PF == 1) {
+        for (int j = 0; j < ntile; ++j) iter(j, ksA, vsA, ksA, vsA);
+    } else {
+        int j = 0;
+        for (; j + 1 < ntile; j += 2) {
+            iter(j, ksB, vsB, ksA, vsA);
+            iter(j + 1, ksA, vsA, ksB, vsB);
+        }
+        if (j < ntile) iter(j, ksB, vsB, ksA, vsA);
     }
     // the K/V stages are free now: per-wave 4 KB staging tile
     unsigned char* stg = smem + wave * IMG;
@@ -615,9 +635,11 @@ int attn2_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t
     using namespace a2;
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
     const size_t smem = qside_smem(Hp, Wp);
-    static bool done = false;
-    if (int e = set_smem(reinterpret_cast<const void*>(fwd_kernel), done)) return e;
-    PA_LAUNCH(fwd_kernel, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, out, (size_t)ldo, lse, L, H, Hp,
+    static const int pf = [] { const char* v = getenv("PA_ATTN_FWD_PF"); return v ? atoi(v) : 2; }();
+    static bool done1 = false, done2 = false;
+    auto kern = pf == 1 ? fwd_kernel<1> : fwd_kernel<2>;
+    if (int e = set_smem(reinterpret_cast<const void*>(kern), pf == 1 ? done1 : done2)) return e;
+    PA_LAUNCH(kern, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, out, (size_t)ldo, lse, L, H, Hp,
               Wp, NRP, scale, th_ld(Hp), etab_phases(Wp));
     return (int)hipGetLastError();
 }

@@ -34,16 +34,22 @@ __global__ void pos_fwd_kernel(const float* __restrict__ M, const float* __restr
     }
     pos[(size_t)l * D + n] = acc;
 }
-__global__ void pos_bwd_kernel(const float* __restrict__ M, const float* __restrict__ g0, const float* __restrict__ g1,
-                               float* __restrict__ dpe, int L, int S, int D) {
-    const int s = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= D) return;
+// block = 64 columns x 4 row-lanes: the token loop (most of M is zero: bicubic support is 4x4 source cells) is split 4 ways and the
+// partial sums are combined through LDS in a fixed order
+__global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ M, const float* __restrict__ g0, const float* __restrict__ g1,
+                                                      float* __restrict__ dpe, int L, int S, int D) {
+    __shared__ float red[4][64];
+    const int s = blockIdx.y, cl = threadIdx.x & 63, rl = threadIdx.x >> 6, n = blockIdx.x * 64 + cl;
     float acc = 0.f;
-    for (int l = 0; l < L; ++l) {
-        const float m = M[(size_t)l * S + s];
-        if (m != 0.f) acc = fmaf(m, g0[(size_t)l * D + n] + g1[(size_t)l * D + n], acc);
+    if (n < D) {
+        for (int l = rl; l < L; l += 4) {
+            const float m = M[(size_t)l * S + s];
+            if (m != 0.f) acc = fmaf(m, g0[(size_t)l * D + n] + g1[(size_t)l * D + n], acc);
+        }
     }
-    dpe[(size_t)s * D + n] = acc;
+    red[rl][cl] = acc;
+    __syncthreads();
+    if (rl == 0 && n < D) dpe[(size_t)s * D + n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 // pe / dpe point at the first non-cls row of pos_embed ([S, D])
 extern "C" int pa_pos_fwd(const float* M, const float* pe, float* pos, int L, int S, int D, hipStream_t st) {
@@ -51,7 +57,7 @@ extern "C" int pa_pos_fwd(const float* M, const float* pe, float* pos, int L, in
     LAUNCH_CHECK();
 }
 extern "C" int pa_pos_bwd(const float* M, const float* gx, const float* gy, float* dpe, int L, int S, int D, hipStream_t st) {
-    PA_LAUNCH(pos_bwd_kernel, dim3((D + 255) / 256, S), dim3(256), 0, st, M, gx, gy, dpe, L, S, D);
+    PA_LAUNCH(pos_bwd_kernel, dim3((D + 63) / 64, S), dim3(256), 0, st, M, gx, gy, dpe, L, S, D);
     LAUNCH_CHECK();
 }
 
@@ -365,9 +371,18 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__
         for (int e = 0; e < 4; ++e) {
             xh[e] = (y[e] - mu) * rs;
             const float z = xh[e] * g4[e] + b4[e];
-            const float a = gelu_f(z);
+            float a, gz;
+            if constexpr (sizeof(T) == 2) {        // bf16 build: fast erf, one exp shared by gelu and gelu' (common.h)
+                float cdf, e2;
+                gelu_parts(z, cdf, e2);
+                a = z * cdf;
+                gz = fmaf(z * 0.39894228040143268f, e2, cdf);
+            } else {
+                a = gelu_f(z);
+                gz = gelu_grad_f(z);
+            }
             const float da = d0 * w4[0][e] + d1 * w4[1][e] + d2 * w4[2][e];
-            const float dz = da * gelu_grad_f(z);
+            const float dz = da * gz;
             ag[e] += dz * xh[e];
             ab[e] += dz;
             aw[0][e] += d0 * a; aw[1][e] += d1 * a; aw[2][e] += d2 * a;

@@ -231,21 +231,26 @@ class HotPath:
         ready([n for n in G if n.startswith("decoder_pred.")])
         dnorm = None
         dx = None
+        dyT_next = None
         for i in reversed(range(c.depth)):
             pre = "blocks.%d." % i
             x0, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc = S.blocks[i]
             S.blocks[i] = None
             R = Bc * L
             ds_a, ds_m = (None, None) if S.drop is None else S.drop[i]
+            # dyT = bf16(ds_m * dx) is emitted by the kernel that produces the final dx of this block's output: the tap
+            # LayerNorm backward, block i+1's norm1 backward (dyT_next), or the stream-merge backward
             if i in c.taps:
                 k = c.taps.index(i)
                 xt, mt, rt = S.taps[k]
-                dx, gb = ops.layernorm_bwd(dconcat[:, k * D:(k + 1) * D], xt, mt, rt, P["norm.weight"], dres=dx, dx=dx)
+                dyT = torch.empty((R, D), dtype=T, device=dev)
+                dx, gb = ops.layernorm_bwd(dconcat[:, k * D:(k + 1) * D], xt, mt, rt, P["norm.weight"], dres=dx, dx=dx, dxT=dyT,
+                                           rowscale=ds_m, rows_per_sample=L)
                 dnorm = gb if dnorm is None else _add_(dnorm, gb)
-            if i == c.merge_idx:
+            elif i == c.merge_idx:
                 dx, dyT = ops.merge_bwd(T, dx, ds_m, L, B * L, D)
             else:
-                dyT = ops.scale_cast(T, dx, ds_m, L)
+                dyT = dyT_next
             # ---- MLP branch: x2 = x1 + s_m * fc2(gelu(fc1(LN2(x1))))
             param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dyT, act)
             dpre = ops.linear_dgrad(dyT, self.w(pre + "mlp.fc2.weight", P), pre=hpre)
@@ -270,7 +275,13 @@ class HotPath:
             param_grads(pre + "attn.qkv.weight", pre + "attn.qkv.bias", dqkv, ln1)
             dln1 = ops.linear_dgrad(dqkv, self.w(pre + "attn.qkv.weight", P), out=dao)
             del dqkv
-            dx, gb = ops.layernorm_bwd(dln1, x0, mean1, rstd1, P[pre + "norm1.weight"], dres=dx, dx=dx)
+            nxt = i - 1
+            dyT_next = None
+            if nxt >= 0 and nxt not in c.taps and nxt != c.merge_idx:
+                dyT_next = torch.empty((R, D), dtype=T, device=dev)
+            ds_next = None if (S.drop is None or nxt < 0) else S.drop[nxt][1]
+            dx, gb = ops.layernorm_bwd(dln1, x0, mean1, rstd1, P[pre + "norm1.weight"], dres=dx, dx=dx, dxT=dyT_next,
+                                       rowscale=ds_next if dyT_next is not None else None, rows_per_sample=L)
             G[pre + "norm1.weight"], G[pre + "norm1.bias"] = gb[0], gb[1]
             del x0, ln1, qkv, ao, x1, ln2, hpre, act
             ready([n for n in G if n.startswith(pre)])

@@ -1,10 +1,9 @@
 #!/bin/bash
-# scratch GPU visit (edited per call); outputs in gpurun_out/
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu -p no:cacheprovider -x -k "conv64" 2>&1 | tail -15 > gpurun_out/tests_conv.log
-timeout 300 python tools/conv_bench.py > gpurun_out/conv_bench.log 2>&1
-timeout 600 python -m pytest tests/test_model_gpu.py -q -m gpu -p no:cacheprovider -x 2>&1 | tail -8 > gpurun_out/tests_model.log
+timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -x 2>&1 | tail -8 > gpurun_out/tests.log
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench.log 2>&1
-cat gpurun_out/tests_conv.log gpurun_out/conv_bench.log gpurun_out/tests_model.log; tail -2 gpurun_out/bench.log
+rm -rf gpurun_out/prof
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof.log 2>&1
+cat gpurun_out/tests.log; tail -1 gpurun_out/bench.log
