@@ -8,9 +8,11 @@ painter_vit_large_patch16_input896x448 (train mode: DropPath active), per-GPU ba
 synthetic inputs already resident in HBM; for N > 1 the gradient all-reduce (RCCL, bucketed, overlapped with backward)
 is inside the step.  Prints ONE JSON line on rank 0 (contract in the task statement):
   value       = N * B * K / t      images/sec, t = max over ranks of the barrier-bracketed wall time of exactly K steps
-  roofline    = the dominant kernel (the 256x256 bf16 MFMA GEMM's weight-gradient instantiation by default) measured
+  roofline    = the dominant kernel family's largest forward instantiation (256x256 bf16 MFMA GEMM, Mlp.fc1 + GELU) measured
                 live with HIP events on the launch stream over the timed region: achieved TFLOP/s = algorithmic
-                FLOPs of those launches / their summed duration; peak = 2500 TFLOP/s dense bf16 MFMA.
+                FLOPs (2.M.N.K per launch) of those launches / their summed duration; peak = 2500 TFLOP/s dense bf16 MFMA;
+                `traffic` = HBM bytes per launch from the PMC pass (profiles/roofline_traffic.json).  `other_kernels`
+                carries the same measurement for the attention forward and the (side-stream, overlapped) weight gradient.
                 `model_mfma_frac` = images/s/GPU * 4.034 TFLOP (attention+MLP fwd+bwd) / 2.5 PFLOP/s.
   cpu_baseline = the CPU oracle (oracle/painter_oracle.py, kind "port"; /root/reference does not exist on the GPU box)
                 timed on the host cores: ONE forward+backward at B=1, 896x448, fp32 (about 10-30 s).
@@ -62,48 +64,42 @@ def synthetic_inputs(batch, H, W, L, seed, device):
 
 
 class KernelTimer:
-    """HIP-event brackets around every launch of one op inside the timed region (events are recorded on torch's
-    current stream, which is the stream every painter_amd kernel is launched on)."""
+    """HIP-event brackets around every launch of a few ops inside the timed region.  Events are recorded on the stream the
+    op is launched on (torch's current stream at the call: the caller's stream, or the engine's side stream for weight
+    gradients).  -> per op: launches, summed duration, algorithmic FLOPs."""
 
-    def __init__(self, ops_mod, which):
-        self.ops, self.which = ops_mod, which
-        self.events, self.flops, self.active = [], 0.0, False
-        self.orig = getattr(ops_mod, "linear_wgrad" if which == "wgrad" else "linear_gelu")
+    FLOPS = {
+        "fc1": lambda a, k: 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[0],                    # linear_gelu(x, w, bias)
+        "attn_fwd": lambda a, k: 4.0 * a[2] * a[4] * a[3] * a[3] * 64,                               # (qkv, rcat, batch, L, heads, ...)
+        "wgrad": lambda a, k: 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[1],                   # linear_wgrad(dy, x)
+    }
+    TARGET = {"fc1": "linear_gelu", "attn_fwd": "attn_fwd", "wgrad": "linear_wgrad"}
+
+    def __init__(self, ops_mod):
+        self.ops, self.active = ops_mod, False
+        self.rec = {k: {"events": [], "flops": 0.0} for k in self.TARGET}
 
     def install(self):
-        timer = self
+        for key, fname in self.TARGET.items():
+            orig = getattr(self.ops, fname)
 
-        def wgrad(dy, x, out=None):
-            if not timer.active:
-                return timer.orig(dy, x, out)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            r = timer.orig(dy, x, out)
-            b.record()
-            timer.events.append((a, b))
-            timer.flops += 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1]
-            return r
+            def wrapped(*a, _orig=orig, _key=key, **kw):
+                if not self.active:
+                    return _orig(*a, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = _orig(*a, **kw)
+                e1.record()
+                self.rec[_key]["events"].append((e0, e1))
+                self.rec[_key]["flops"] += self.FLOPS[_key](a, kw)
+                return r
 
-        def fc1(x, w, bias, need_pre=True):
-            if not timer.active:
-                return timer.orig(x, w, bias, need_pre)
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            r = timer.orig(x, w, bias, need_pre)
-            b.record()
-            timer.events.append((a, b))
-            timer.flops += 2.0 * x.shape[0] * x.shape[1] * w.shape[0]
-            return r
+            setattr(self.ops, fname, wrapped)
 
-        if self.which == "wgrad":
-            self.ops.linear_wgrad = wgrad
-        else:
-            self.ops.linear_gelu = fc1
-
-    def result(self):
-        ms = sum(a.elapsed_time(b) for a, b in self.events)
-        n = len(self.events)
-        return n, ms, (self.flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+    def result(self, key):
+        ev = self.rec[key]["events"]
+        ms = sum(a.elapsed_time(b) for a, b in ev)
+        return len(ev), ms, (self.rec[key]["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
 
 
 def cpu_baseline():
@@ -129,7 +125,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE configs[1]: 8)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--roofline-kernel", default="wgrad", choices=["wgrad", "fc1"])
+    ap.add_argument("--roofline-kernel", default="fc1", choices=["fc1", "attn_fwd", "wgrad"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval", action="store_true", help="eval mode (no DropPath)")
     args = ap.parse_args()
@@ -162,7 +158,7 @@ def main():
         loss.backward()
         return loss
 
-    timer = KernelTimer(ops, args.roofline_kernel)
+    timer = KernelTimer(ops)
     timer.install()
     for _ in range(args.warmup):
         step()
@@ -189,18 +185,30 @@ def main():
 
     if rank == 0:
         ips = world * args.batch * args.steps / dt
-        n, kms, tf = timer.result()
+        n, kms, tf = timer.result(args.roofline_kernel)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        kname = ("g256::gemm256_kernel<true,true,Epi4Slab> (nn.Linear weight gradient dW = dY^T.X, split over rows; the largest "
-                 "single kernel of the step)" if args.roofline_kernel == "wgrad"
-                 else "g256::gemm256_kernel<false,false,Epi4BiasGelu> (fc1 forward + erf GELU)")
+        KNAME = {
+            "fc1": "g256::gemm256_kernel<false,false,Epi4BiasGelu> (Mlp.fc1 forward: [R,1024]x[1024,4096] + bias + erf-GELU, writes "
+                   "pre-activation and activation; the largest forward instantiation of the 256x256 bf16 MFMA GEMM that carries "
+                   "52% of the step's kernel time; forward launches do not overlap the side stream, so the event time is the "
+                   "kernel's own)",
+            "attn_fwd": "a2::fwd_kernel (fused attention forward with decomposed rel-pos bias)",
+            "wgrad": "g256::gemm256_kernel<true,true,Epi4Slab> (weight gradient dW = dY^T.X on the side stream: runs CONCURRENTLY "
+                     "with the main stream's dgrad/attention kernels, so its duration includes time-sharing)",
+        }
+        kname = KNAME[args.roofline_kernel]
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC pass (tools_gpu_round.sh), per launch
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC pass (tools/pmc_traffic.py), bytes per launch
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(args.roofline_kernel)
+                traffic = json.load(open(tpath)).get(args.roofline_kernel, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
+        more = {}
+        for k in KernelTimer.TARGET:
+            if k != args.roofline_kernel:
+                nn_, ms_, tf_ = timer.result(k)
+                more[k] = {"launches": nn_, "kernel_ms_total": round(ms_, 3), "achieved": round(tf_, 2), "frac": round(tf_ / peak, 4)}
         out = {
             "metric": "images/sec (896x448 pairs) ViT-L fwd+bwd",
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -212,7 +220,8 @@ def main():
                        "mode": "eval" if args.eval else "train (DropPath 0.1)", "parallelism": "dp%d" % world,
                        "grad_allreduce": "RCCL bucketed, overlapped with backward" if world > 1 else "n/a"},
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                         "traffic": traffic, "kernel": kname, "launches": n, "kernel_ms_total": round(kms, 3)},
+                         "traffic": traffic, "kernel": kname, "launches": n, "kernel_ms_total": round(kms, 3),
+                         "avg_us": round(kms / max(n, 1) * 1e3, 2), "other_kernels": more},
             "model_mfma_frac": round(ips / world * FLOP_BLOCKS_FWD_BWD / (peak * 1e12), 4),
             "model_tflops_per_gpu": round(ips / world * FLOP_MODEL_FWD_BWD / 1e12, 2),
             "loss": round(lossv, 6),

@@ -31,6 +31,21 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
+// 1-D grid of (row blocks per head) x (batch * heads) workgroups.  Workgroup n runs on XCD n % 8 (MI355X dispatch order), and each
+// XCD has its own 4 MB L2: give every XCD a contiguous run of (head, row block) pairs, row block fastest, so that all row blocks
+// of a head stream the head's K/V (or Q/dO/aux) tiles through ONE L2 instead of eight (7-8 heads x 0.4 MB live per XCD).
+// PA_ATTN_XCD=0 (diagnostics) keeps the plain order.
+DEVI void wg_coords(int nblk, int xcd_map, int& blk, int& bh) {
+    const int n = blockIdx.x, total = gridDim.x;
+    int v = n;
+    if (xcd_map) {
+        const int xq = total >> 3, xr = total & 7, xcd = n & 7;
+        v = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (n >> 3);
+    }
+    bh = v / nblk;
+    blk = v - bh * nblk;
+}
+
 // ---- tile image: 32 rows x 128 B, 16-B chunk index XORed with a bijection of row bits 1..3
 DEVI int vsw(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
 
@@ -164,14 +179,16 @@ DEVI void write_rows(const unsigned char* stg, bf16* dst, size_t ld, int lane) {
 template <int PF>
 __global__ __launch_bounds__(NT, 2) void fwd_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
                                                   bf16* __restrict__ out, size_t ldo, float* __restrict__ lse, int L, int H, int Hp,
-                                                  int Wp, int NRP, float scale, int thld, int nphase) {
+                                                  int Wp, int NRP, float scale, int thld, int nphase, int nblk, int xcd_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, row = wave * 32 + (lane & 31);
-    const int bh = blockIdx.y, b = bh / H, h = bh % H, D = H * ATT_HD;
+    int blk, bh;
+    wg_coords(nblk, xcd_map, blk, bh);
+    const int b = bh / H, h = bh % H, D = H * ATT_HD;
     const bf16* base = qkv + (size_t)b * L * ldq + h * ATT_HD;
     const bf16* kbase = base + D;
     const bf16* vbase = base + 2 * D;
-    const int qt = blockIdx.x * NW + wave;
+    const int qt = blk * NW + wave;
     const bool valid = qt * 32 < L;
     const int q = qt * 32 + (lane & 31);
     unsigned char* twb = smem + 2 * STAGE_QK + (size_t)row * Wp * 4;
@@ -313,14 +330,17 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
                                                      const bf16* __restrict__ rcatT, const bf16* __restrict__ dout, size_t lddo,
                                                      const float* __restrict__ lse, const float* __restrict__ delta,
                                                      bf16* __restrict__ dqkv, bf16* __restrict__ dG, unsigned char* __restrict__ aux,
-                                                     int L, int H, int Hp, int Wp, int NRP, float scale, int thld, int nphase) {
+                                                     int L, int H, int Hp, int Wp, int NRP, float scale, int thld, int nphase, int nblk,
+                                                     int xcd_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, row = wave * 32 + (lane & 31);
-    const int bh = blockIdx.y, b = bh / H, h = bh % H, D = H * ATT_HD;
+    int blk, bh;
+    wg_coords(nblk, xcd_map, blk, bh);
+    const int b = bh / H, h = bh % H, D = H * ATT_HD;
     const bf16* base = qkv + (size_t)b * L * ldq + h * ATT_HD;
     const bf16* kbase = base + D;
     const bf16* vbase = base + 2 * D;
-    const int qt = blockIdx.x * NW + wave;
+    const int qt = blk * NW + wave;
     const bool valid = qt * 32 < L;
     const int q = qt * 32 + (lane & 31);
     const int qh = q / Wp, qw = q % Wp;
@@ -491,13 +511,15 @@ constexpr int AH_LD = 144, AW_LD = 144;    // LDS row strides (bytes) of the tra
 template <int MINW>
 __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ dout,
                                                       size_t lddo, const unsigned char* __restrict__ aux, bf16* __restrict__ dqkv,
-                                                      int L, int H, int Hp, int Wp, float scale) {
+                                                      int L, int H, int Hp, int Wp, float scale, int nblk, int xcd_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
-    const int bh = blockIdx.y, b = bh / H, h = bh % H, D = H * ATT_HD;
+    int blk, bh;
+    wg_coords(nblk, xcd_map, blk, bh);
+    const int b = bh / H, h = bh % H, D = H * ATT_HD;
     const bf16* qbase = qkv + (size_t)b * L * ldq + h * ATT_HD;
     const bf16* dobase = dout + (size_t)b * L * lddo + h * ATT_HD;
-    const int kt = blockIdx.x * NW + wave;
+    const int kt = blk * NW + wave;
     const bool valid = kt * 32 < L;
     const int key = kt * 32 + (lane & 31);
     const int khl = key / Wp, kwl = key % Wp;
@@ -628,6 +650,10 @@ static int th_ld(int Hp) {
     if (((s / 2) & 1) == 0) s += 2;
     return s;
 }
+static int xcd_map_on() {
+    static const int v = [] { const char* e = getenv("PA_ATTN_XCD"); return e ? atoi(e) : 1; }();
+    return v;
+}
 static size_t qside_smem(int Hp, int Wp) { return 2 * a2::STAGE_QK + (size_t)a2::ROWS * (Wp * 4 + th_ld(Hp) * 2) + 1024; }
 
 int attn2_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t ldo, float* lse, int Bn, int L, int H, int Hp, int Wp,
@@ -639,8 +665,9 @@ int attn2_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t
     static bool done1 = false, done2 = false;
     auto kern = pf == 1 ? fwd_kernel<1> : fwd_kernel<2>;
     if (int e = set_smem(reinterpret_cast<const void*>(kern), pf == 1 ? done1 : done2)) return e;
-    PA_LAUNCH(kern, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, out, (size_t)ldo, lse, L, H, Hp,
-              Wp, NRP, scale, th_ld(Hp), etab_phases(Wp));
+    const int nblk = (L / 32 + NW - 1) / NW;
+    PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, out, (size_t)ldo, lse, L, H, Hp,
+              Wp, NRP, scale, th_ld(Hp), etab_phases(Wp), nblk, xcd_map_on());
     return (int)hipGetLastError();
 }
 
@@ -662,8 +689,9 @@ int attn2_bwd(const bf16* qkv, int64_t ldq, const bf16* rcat, const bf16* rcatT,
         auto kern = minw == 3 ? bwd_dq_kernel<3> : bwd_dq_kernel<2>;
         static bool done2 = false, done3 = false;
         if ((e = set_smem(reinterpret_cast<const void*>(kern), minw == 3 ? done3 : done2))) return e;
-        PA_LAUNCH(kern, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, rcatT, dout, (size_t)lddo,
-                  lse, delta, dqkv, dG, reinterpret_cast<unsigned char*>(aux), L, H, Hp, Wp, NRP, scale, th_ld(Hp), nphase);
+        const int nblk = (L / 32 + NW - 1) / NW;
+        PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, rcatT, dout, (size_t)lddo,
+                  lse, delta, dqkv, dG, reinterpret_cast<unsigned char*>(aux), L, H, Hp, Wp, NRP, scale, th_ld(Hp), nphase, nblk, xcd_map_on());
         if ((e = (int)hipGetLastError())) return e;
     }
     {
@@ -673,8 +701,9 @@ int attn2_bwd(const bf16* qkv, int64_t ldq, const bf16* rcat, const bf16* rcatT,
         auto kern = minw == 3 ? bwd_dkv_kernel<3> : bwd_dkv_kernel<2>;
         static bool done2 = false, done3 = false;
         if ((e = set_smem(reinterpret_cast<const void*>(kern), minw == 3 ? done3 : done2))) return e;
-        PA_LAUNCH(kern, dim3((L / 32 + NW - 1) / NW, Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, dout, (size_t)lddo,
-                  reinterpret_cast<const unsigned char*>(aux), dqkv, L, H, Hp, Wp, scale);
+        const int nblk = (L / 32 + NW - 1) / NW;
+        PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, dout, (size_t)lddo,
+                  reinterpret_cast<const unsigned char*>(aux), dqkv, L, H, Hp, Wp, scale, nblk, xcd_map_on());
         return (int)hipGetLastError();
     }
 }

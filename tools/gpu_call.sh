@@ -2,8 +2,9 @@
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -x 2>&1 | tail -8 > gpurun_out/tests.log
+timeout 300 python -m pytest tests/test_kernels_gpu.py -q -m gpu -p no:cacheprovider -x -k "streamk or gemm256 or linear" 2>&1 | tail -15 > gpurun_out/tests_sk.log
+cat gpurun_out/tests_sk.log
+timeout 300 python tools/gemm_probe.py sk > gpurun_out/probe_sk.log 2>&1
+cat gpurun_out/probe_sk.log
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench.log 2>&1
-rm -rf gpurun_out/prof
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o r1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/prof.log 2>&1
-cat gpurun_out/tests.log; tail -1 gpurun_out/bench.log
+tail -1 gpurun_out/bench.log | cut -c1-400
