@@ -118,6 +118,41 @@ def cpu_baseline():
                       "one forward+backward, %.1f s, no warm-up" % dt}
 
 
+def optimizer_step_ms(model, step_fn):
+    """Reported next to the headline number, never inside it ("+ optimizer step reported separately"):
+    the fused unscale + clip(3.0) + AdamW of painter_amd/optim.py (52 layer-decay groups as util/lr_decay.py builds them) vs
+    torch.optim.AdamW + clip_grad_norm_ on the same gradients, HIP events, 3 runs each."""
+    from painter_amd import optim as PO
+    nl = len(model.blocks) + 1
+    groups = {}
+    for n, p in model.named_parameters():                       # util/lr_decay.py:15-76
+        lid = 0 if (n in ("cls_token", "pos_embed") or n.startswith("patch_embed")) else (int(n.split(".")[1]) + 1 if n.startswith("blocks") else nl)
+        nd = p.ndim == 1 or n in ("pos_embed", "cls_token")
+        key = (lid, nd)
+        groups.setdefault(key, {"params": [], "weight_decay": 0.0 if nd else 0.05, "lr": 1e-3 * 0.8 ** (nl - lid)})["params"].append(p)
+    step_fn()                                                    # fresh gradients
+    res = {}
+    for name, opt in (("fused", PO.AdamW(list(groups.values()), lr=1e-3, betas=(0.9, 0.999))),
+                      ("torch", torch.optim.AdamW(list(groups.values()), lr=1e-3, betas=(0.9, 0.999)))):
+        ts = []
+        for _ in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            if name == "fused":
+                opt.grad_sumsq()
+                opt.step(max_norm=3.0)
+            else:
+                torch.nn.utils.clip_grad_norm_(model.parameters(), 3.0)
+                opt.step()
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        res[name + "_ms"] = round(min(ts[1:]), 3)
+        del opt
+    res["note"] = "unscale + global-norm clip + AdamW over 370.7 M fp32 parameters; not part of `value`"
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -226,6 +261,8 @@ def main():
             "model_tflops_per_gpu": round(ips / world * FLOP_MODEL_FWD_BWD / 1e12, 2),
             "loss": round(lossv, 6),
         }
+        if world == 1 and args.dtype == "bf16":
+            out["optimizer_step"] = optimizer_step_ms(model, step)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

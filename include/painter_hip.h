@@ -164,6 +164,34 @@ int pa_loss_bwd(const float* pred, const float* tgts, const float* valid, const 
 /* patchify (models_painter.py:355-368): f32 NCHW -> [B, L, P*P*3] */
 int pa_patchify(const float* img, float* out, int batch, int Hp, int Wp, int P, hipStream_t stream);
 
+/* ---- Optimizer step: GradScaler.unscale_ + clip_grad_norm_ + AdamW over the layer-decay groups in two passes.
+ * Replaces Painter/util/misc.py:256-268 (NativeScalerWithGradNormCount.__call__) acting on the torch.optim.AdamW of
+ * Painter/main_train.py:344-348 (parameter groups: util/lr_decay.py:15-61; schedule: util/lr_sched.py:9-21).
+ * table: DEVICE array of ntensors records, first_chunk = running sum of ceil(n / pa_opt_chunk_elems()); nchunks = their total.
+ * g == NULL marks a parameter without gradient (skipped).  All tensors fp32, contiguous. */
+typedef struct PaOptTensor {
+    void* p; const void* g; void* m; void* v;    /* parameter, gradient, exp_avg, exp_avg_sq */
+    int64_t n;                                   /* elements */
+    int32_t group;                               /* index into PaOptGroups */
+    int32_t first_chunk;
+} PaOptTensor;
+typedef struct PaOptGroups {                     /* HOST struct, passed by value to the kernel: at most 64 parameter groups */
+    float lr[64], wd[64];                        /* learning rate (already times lr_scale), weight decay */
+    int32_t active[64];                          /* 1 = the group has gradients in this step (its step count advances) */
+} PaOptGroups;
+int pa_opt_chunk_elems(void);
+int64_t pa_grad_sumsq_workspace_bytes(int nchunks);
+/* out2 (device, 2 floats): [0] = sum over all gradients of g^2 (as stored, i.e. still multiplied by the loss scale),
+ * [1] = 0 if every gradient is finite */
+int pa_grad_sumsq(const PaOptTensor* table, int ntensors, int nchunks, float* out2, void* workspace, hipStream_t stream);
+/* steps: DEVICE float[64], the per-group AdamW step counts (advanced here unless the step is skipped);
+ * norm_info = out2 of pa_grad_sumsq or NULL (no clipping / no finiteness gate); grad_scale = device scalar the gradients are
+ * divided by, or NULL; found_inf = device scalar, nonzero skips the step (torch GradScaler protocol), or NULL;
+ * max_norm <= 0 disables clipping.  groups is a HOST pointer. */
+int pa_adamw_step(const PaOptTensor* table, int ntensors, int nchunks, const PaOptGroups* groups, float beta1, float beta2,
+                  float eps, float* steps, const float* norm_info, const float* grad_scale, const float* found_inf,
+                  float max_norm, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,10 +4,10 @@ Painter/main_train.py:340).
 One process per GPU, `torch.distributed` backend "nccl" (= RCCL on ROCm, xGMI between the 8 GPUs of a node).  The
 path shards by samples, so the only exchange is the gradient all-reduce: `GradSync` is called by the engine's
 backward as soon as a bucket of parameter gradients has been ENQUEUED (decoder head first, then blocks 23 -> 0, then
-the patch/token parameters), flattens the bucket into one contiguous fp32 message and starts an asynchronous
-all-reduce(AVG).  RCCL runs it on its own stream, ordered after the producing kernels, so the exchange of bucket k
+the patch/token parameters) and starts asynchronous all-reduce(AVG)s: the weight matrices in place (no flattening copy), the
+bucket's small tensors flattened into one message.  RCCL runs it on its own stream, ordered after the producing kernels, so the exchange of bucket k
 overlaps the backward kernels of bucket k+1.  `finish()` makes the compute stream wait for all buckets and hands the
-averaged gradients back as views into the flat messages (no unflatten copy).
+averaged gradients back (in place, or as views into the flat message).
 
 Bucket = one transformer block (~12.6 M params = 50 MB fp32) -- large messages because a ring/tree over
 point-to-point xGMI links is per-link bandwidth bound, not latency bound; decoder_embed's 268 MB gradient is its own
@@ -35,24 +35,38 @@ class GradSync:
     def world_size(self):
         return dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
 
-    def ready(self, G, names):
-        """Gradients `names` of dict G are enqueued: start their all-reduce, replace them by views of the flat message."""
-        if not self.enabled or self.world_size == 1:
-            return
-        ts = [G[n] for n in names]
-        flat = torch.cat([t.reshape(-1) for t in ts])                   # one contiguous fp32 message
+    BIG = 1 << 20          # gradients of at least this many elements are exchanged in place, without a flattening copy
+
+    def _reduce(self, t):
         backend = dist.get_backend(self.group)
         if self.average and backend == "nccl":
-            work = dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-            post = None
-        else:
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            post = (1.0 / self.world_size) if self.average else None    # gloo (CPU tests) has no AVG
-        off = 0
-        for n, t in zip(names, ts):
-            G[n] = flat[off:off + t.numel()].view(t.shape)
-            off += t.numel()
-        self._pending.append((work, flat, post))
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None
+        work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return work, ((1.0 / self.world_size) if self.average else None)    # gloo (CPU tests) has no AVG
+
+    def ready(self, G, names):
+        """Gradients `names` of dict G are enqueued on the current stream: start their all-reduce.  Weight matrices (>= 1 M
+        elements: 4-268 MB messages, large enough to run at link bandwidth) are reduced in place; the bucket's small tensors
+        (biases, LayerNorm, rel-pos tables) are flattened into one message and replaced by views of it."""
+        if not self.enabled or self.world_size == 1:
+            return
+        small = []
+        for n in names:
+            t = G[n]
+            if t.numel() >= self.BIG and t.is_contiguous():
+                work, post = self._reduce(t)
+                self._pending.append((work, t, post))
+            else:
+                small.append(n)
+        if small:
+            ts = [G[n] for n in small]
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            work, post = self._reduce(flat)
+            off = 0
+            for n, t in zip(small, ts):
+                G[n] = flat[off:off + t.numel()].view(t.shape)
+                off += t.numel()
+            self._pending.append((work, flat, post))
 
     def finish(self):
         for work, flat, post in self._pending:

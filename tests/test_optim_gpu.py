@@ -1,0 +1,101 @@
+"""GPU parity of the fused optimizer step (csrc/optim.hip through painter_amd/optim.py) against the CPU oracle, which is itself
+pinned to torch.optim.AdamW + clip_grad_norm_ (tests/test_optim_cpu.py).  fp32 elementwise arithmetic in the same operation
+order: gate 2e-6 relative (fma contraction / reciprocal forms differ in the last bit)."""
+import pytest
+import torch
+
+from oracle import optim_oracle as OO
+
+pytestmark = pytest.mark.gpu
+
+if torch.cuda.is_available():
+    from painter_amd import optim as PO
+
+SHAPES = [(1024, 1024), (3072,), (5, 7), (64, 64, 3, 3), (1, 197, 64), (8193,), (3,)]
+
+
+def _make(seed):
+    g = torch.Generator().manual_seed(seed)
+    params = [torch.randn(s, generator=g) for s in SHAPES]
+    cfg = [(1e-3 * (0.75 ** (i % 3)), 0.05 if len(s) > 1 else 0.0) for i, s in enumerate(SHAPES)]
+    return g, params, cfg
+
+
+@pytest.mark.parametrize("scale,clip", [(65536.0, 3.0), (1.0, None), (128.0, 0.05)])
+def test_fused_adamw_vs_oracle(scale, clip):
+    g, params, cfg = _make(3)
+    dev_p = [torch.nn.Parameter(p.clone().cuda()) for p in params]
+    opt = PO.AdamW([{"params": [p], "lr": lr, "weight_decay": wd} for p, (lr, wd) in zip(dev_p, cfg)], lr=1e-3, betas=(0.9, 0.95))
+    ora_p = [p.clone() for p in params]
+    state = [dict(step=0, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p)) for p in params]
+    scale_t = torch.tensor(scale, device="cuda")
+    for k in range(3):
+        grads = [torch.randn(s, generator=g) * (5.0 if k == 1 else 0.2) * scale for s in SHAPES]
+        for p, gr in zip(dev_p, grads):
+            p.grad = gr.clone().cuda()
+        info = opt.grad_sumsq()
+        opt.step(grad_scale=scale_t, max_norm=clip)
+        norm, skipped = OO.scaled_clipped_step(ora_p, grads, state, cfg, scale, clip, 0.9, 0.95, 1e-8)
+        assert not skipped and float(info[1]) == 0.0
+        dev_norm = float(torch.sqrt(info[0])) / scale
+        assert abs(dev_norm - float(norm)) <= 2e-6 * float(norm)          # fp32 per-chunk sums, float64 across chunks
+        for a, b in zip(dev_p, ora_p):
+            assert torch.allclose(a.detach().cpu(), b, rtol=2e-6, atol=1e-7)
+    for p, st in zip(dev_p, state):
+        assert torch.allclose(opt.state[p]["exp_avg"].cpu(), st["exp_avg"], rtol=2e-6, atol=1e-7)      # cancellation in m + (g - m)(1 - b1)
+        assert torch.allclose(opt.state[p]["exp_avg_sq"].cpu(), st["exp_avg_sq"], rtol=2e-6, atol=1e-9)
+        assert float(opt.state[p]["step"]) == float(st["step"])
+
+
+def test_fused_step_skips_on_inf_and_scaler_backs_off():
+    g, params, cfg = _make(4)
+    dev_p = [torch.nn.Parameter(p.clone().cuda()) for p in params]
+    opt = PO.AdamW([{"params": [p], "lr": lr, "weight_decay": wd} for p, (lr, wd) in zip(dev_p, cfg)], lr=1e-3)
+    scaler = PO.NativeScalerWithGradNormCount(init_scale=1024.0)
+    # a scalar "loss" whose gradient w.r.t. every parameter is known: sum(w_i * p_i)
+    ws = [torch.randn(s, generator=g).cuda() for s in SHAPES]
+    loss = sum((w * p).sum() for w, p in zip(ws, dev_p))
+    norm = scaler(loss, opt, clip_grad=3.0, parameters=dev_p)
+    ref_norm = torch.sqrt(sum((w.double() ** 2).sum() for w in ws))
+    assert abs(float(norm) - float(ref_norm)) < 1e-5 * float(ref_norm)
+    assert float(scaler.state_dict()["scale"]) == 1024.0 and float(opt.state[dev_p[0]]["step"]) == 1.0
+    before = [p.detach().clone() for p in dev_p]
+    opt.zero_grad()
+    ws[2].view(-1)[1] = float("nan")
+    loss = sum((w * p).sum() for w, p in zip(ws, dev_p))
+    scaler(loss, opt, clip_grad=3.0, parameters=dev_p)
+    assert all(torch.equal(a, b.detach()) for a, b in zip(before, dev_p))            # step skipped on the device
+    assert float(opt.state[dev_p[0]]["step"]) == 1.0                                  # ... and not counted
+    assert float(scaler.state_dict()["scale"]) == 512.0                               # GradScaler back-off
+
+
+def test_torch_gradscaler_drives_fused_adamw_and_state_dict_roundtrip():
+    """The unchanged reference scaler (util/misc.py:252-270) on top of our optimizer, and torch.optim.AdamW checkpoint interchange."""
+    g, params, cfg = _make(5)
+    dev_p = [torch.nn.Parameter(p.clone().cuda()) for p in params]
+    ref_p = [torch.nn.Parameter(p.clone().cuda()) for p in params]
+    groups = lambda ps: [{"params": [p], "lr": lr, "weight_decay": wd} for p, (lr, wd) in zip(ps, cfg)]
+    opt, ref = PO.AdamW(groups(dev_p), lr=1e-3, betas=(0.9, 0.95)), torch.optim.AdamW(groups(ref_p), lr=1e-3, betas=(0.9, 0.95))
+    s1, s2 = torch.cuda.amp.GradScaler(init_scale=256.0), torch.cuda.amp.GradScaler(init_scale=256.0)
+    ws = [torch.randn(s, generator=g).cuda() for s in SHAPES]
+    for it in range(2):
+        for ps, o, sc in ((dev_p, opt, s1), (ref_p, ref, s2)):
+            o.zero_grad()
+            loss = sum((w * p * p).sum() for w, p in zip(ws, ps))
+            sc.scale(loss).backward()
+            sc.unscale_(o)
+            torch.nn.utils.clip_grad_norm_(ps, 3.0)
+            sc.step(o)
+            sc.update()
+        for a, b in zip(dev_p, ref_p):
+            assert torch.allclose(a.detach(), b.detach(), rtol=2e-6, atol=1e-7)
+    # checkpoint written by torch.optim.AdamW loads into ours (and continues identically)
+    opt2 = PO.AdamW(groups(dev_p), lr=1e-3, betas=(0.9, 0.95))
+    import copy
+    opt2.load_state_dict(copy.deepcopy(ref.state_dict()))     # state_dict() hands out the live tensors; a checkpoint file would not
+    for ps, o in ((dev_p, opt2), (ref_p, ref)):
+        o.zero_grad()
+        sum((w * p * p).sum() for w, p in zip(ws, ps)).backward()
+        o.step()
+    for a, b in zip(dev_p, ref_p):
+        assert torch.allclose(a.detach(), b.detach(), rtol=2e-6, atol=1e-7)

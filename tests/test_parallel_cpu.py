@@ -28,6 +28,7 @@ def _worker(rank, world, port, q):
     G = {n: torch.randn(s, generator=g) for n, s in zip(names, shapes)}
     local = {n: t.clone() for n, t in G.items()}
     sync = parallel.GradSync()
+    sync.BIG = 40                       # (16, 8) and (12, 4) take the in-place path, the rest the flattened small-tensor message
     sync.ready(G, names[:1])            # decoder bucket first, as the engine's backward does
     sync.ready(G, names[1:3])
     sync.ready(G, names[3:])
