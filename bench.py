@@ -178,7 +178,7 @@ def main():
     randomize_parameters(model, seed=1)
     model = model.to(dev)
     model.train(not args.eval)
-    if world > 1:
+    if world > 1 or parallel._SELFTEST:
         import torch.distributed as dist
         for p in model.parameters():                      # C2: replicas start identical (same seed; broadcast anyway)
             dist.broadcast(p.data, src=0)
@@ -199,7 +199,7 @@ def main():
         step()
 
     def barrier():
-        if world > 1:
+        if world > 1 or parallel._SELFTEST:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -213,7 +213,7 @@ def main():
     dt = time.perf_counter() - t0
     timer.active = False
     lossv = float(loss.item())
-    if world > 1:
+    if world > 1 or parallel._SELFTEST:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
@@ -266,7 +266,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or parallel._SELFTEST:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -209,6 +209,8 @@ class HotPath:
                 sync.ready(G, names)
                 return
             side.wait_stream(main)                 # the bucket's gradients come from both streams
+            for n in names:                        # main-stream allocations (LayerNorm / rel-pos / tail gradients) are read by the
+                G[n].record_stream(side)           # side stream's flattening copy: keep the allocator from recycling them early
             with torch.cuda.stream(side):
                 sync.ready(G, names)
 

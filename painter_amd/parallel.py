@@ -21,6 +21,12 @@ import torch
 import torch.distributed as dist
 
 
+# PAINTER_AMD_DDP_SELFTEST=1: run the exchange even in a 1-rank group (exercises RCCL init, AVG all-reduce, the stream ordering
+# and the in-place / flattened paths on a single-GPU box; the result must equal the local gradient)
+import os as _os
+_SELFTEST = _os.environ.get("PAINTER_AMD_DDP_SELFTEST", "0") == "1"
+
+
 class GradSync:
     def __init__(self, process_group=None, average=True):
         self.group = process_group
@@ -48,7 +54,7 @@ class GradSync:
         """Gradients `names` of dict G are enqueued on the current stream: start their all-reduce.  Weight matrices (>= 1 M
         elements: 4-268 MB messages, large enough to run at link bandwidth) are reduced in place; the bucket's small tensors
         (biases, LayerNorm, rel-pos tables) are flattened into one message and replaced by views of it."""
-        if not self.enabled or self.world_size == 1:
+        if not self.enabled or (self.world_size == 1 and not _SELFTEST):
             return
         small = []
         for n in names:
@@ -81,8 +87,11 @@ def init_distributed(backend=None):
     mirrors util/misc.py:217-249 without the SLURM/OMPI parsing."""
     import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not _SELFTEST:
         return 0, 0, 1
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
     rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -168,3 +168,17 @@ def test_vit_large_bf16_loss_and_pred_yardstick():
     stride = int(fx[case + "pred_stride"])
     assert G.rel_fro(flat[::stride], fx[case + "pred_sample"]) < 3e-2      # reference's own bf16 deviation: 1e-2
     G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-1, 5e-2, 1e-1)
+
+
+def test_ddp_gradient_path_single_rank_rccl():
+    """The multi-GPU gradient exchange exercised on one GPU (tools/ddp_selftest.py): 1-rank RCCL group, GradSync driven from the
+    two-stream backward; gradients must be bit-identical to the run without the exchange (this caught a cross-stream allocator
+    race on the flattened small-tensor message)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PAINTER_AMD_DDP_SELFTEST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "ddp_selftest.py")], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "DDP selftest OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])

@@ -1,0 +1,46 @@
+"""Single-GPU exercise of the multi-GPU gradient path (run with PAINTER_AMD_DDP_SELFTEST=1): a 1-rank RCCL group, GradSync
+started from inside the two-stream backward (in-place all-reduce of the weight matrices, flattened small tensors), then the same
+step without the exchange -- gradients must be bit-identical (AVG over one rank is the identity)."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+os.environ["PAINTER_AMD_DDP_SELFTEST"] = "1"
+import bench  # noqa: E402
+from painter_amd import models_painter, parallel  # noqa: E402
+
+
+def main():
+    rank, local, world = parallel.init_distributed()
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    m = models_painter.painter_vit_large_patch16_input896x448(compute_dtype="bf16")
+    bench.randomize_parameters(m, seed=1)
+    m = m.to(dev).eval()                   # eval: no DropPath randomness between the two runs
+    c = m._cfg
+    inp = bench.synthetic_inputs(2, c.H, c.W, c.L, 1234, dev)
+
+    def grads(sync):
+        m.grad_sync = sync
+        for p in m.parameters():
+            p.grad = None
+        loss, _, _ = m(inp[0], inp[1], bool_masked_pos=inp[2], valid=inp[3])
+        loss.backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in m.named_parameters()}, float(loss)
+
+    ga, la = grads(parallel.GradSync())
+    gb, lb = grads(None)
+    bad = [n for n in ga if not torch.equal(ga[n], gb[n])]
+    print("world", torch.distributed.get_world_size(), "backend", torch.distributed.get_backend(), "loss", la, lb,
+          "tensors", len(ga), "mismatching", bad[:5])
+    assert not bad and la == lb
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    print("DDP selftest OK")
+
+
+if __name__ == "__main__":
+    main()

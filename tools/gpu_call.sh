@@ -2,5 +2,7 @@
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 300 python -m pytest tests/test_optim_gpu.py -q -m gpu -p no:cacheprovider --tb=short 2>&1 | tail -12 > gpurun_out/tests_opt.log
-cat gpurun_out/tests_opt.log
+timeout 300 python tools/ddp_selftest.py > gpurun_out/ddp.log 2>&1
+tail -4 gpurun_out/ddp.log
+PAINTER_AMD_DDP_SELFTEST=1 timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/bench_ddp1.log 2>&1
+tail -1 gpurun_out/bench_ddp1.log | cut -c1-200
