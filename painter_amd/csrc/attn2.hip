@@ -176,8 +176,10 @@ DEVI void write_rows(const unsigned char* stg, bf16* dst, size_t ld, int lane) {
 
 // =============================================================================================== forward
 // LDS: [K img | V img] x 2 stages (16 KB) | tw f32 [128][Wp] | th bf16 [128][thld] | run table [nphase][2][4] u32
-template <int PF>
-__global__ __launch_bounds__(NT, 2) void fwd_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
+// STAGES = 2: K/V double-buffered in LDS, one barrier per key tile, 3 workgroups per CU.  STAGES = 1: one K/V stage (two barriers
+// per tile), 38 KB of LDS -> 4 workgroups per CU (needs <= 128 VGPRs: PF = 1).
+template <int PF, int STAGES>
+__global__ __launch_bounds__(NT, STAGES == 1 ? 4 : 2) void fwd_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
                                                   bf16* __restrict__ out, size_t ldo, float* __restrict__ lse, int L, int H, int Hp,
                                                   int Wp, int NRP, float scale, int thld, int nphase, int nblk, int xcd_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -191,9 +193,9 @@ __global__ __launch_bounds__(NT, 2) void fwd_kernel(const bf16* __restrict__ qkv
     const int qt = blk * NW + wave;
     const bool valid = qt * 32 < L;
     const int q = qt * 32 + (lane & 31);
-    unsigned char* twb = smem + 2 * STAGE_QK + (size_t)row * Wp * 4;
-    unsigned char* thb = smem + 2 * STAGE_QK + ROWS * Wp * 4 + (size_t)row * thld * 2;
-    uint32_t* rtab = reinterpret_cast<uint32_t*>(smem + 2 * STAGE_QK + ROWS * Wp * 4 + ROWS * thld * 2);
+    unsigned char* twb = smem + STAGES * STAGE_QK + (size_t)row * Wp * 4;
+    unsigned char* thb = smem + STAGES * STAGE_QK + ROWS * Wp * 4 + (size_t)row * thld * 2;
+    uint32_t* rtab = reinterpret_cast<uint32_t*>(smem + STAGES * STAGE_QK + ROWS * Wp * 4 + ROWS * thld * 2);
     LaneAddr la;
     la.init(lane);
     build_rtab(rtab, nphase, Wp, tid);
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(NT, 2) void fwd_kernel(const bf16* __restrict__ qkv
             kl.load(kbase + (size_t)jn * 32 * ldq, ldq, tid);
             vl.load(vbase + (size_t)jn * 32 * ldq, ldq, tid);
         }
-        const unsigned char* kimg = smem + (j & 1) * STAGE_QK;
+        const unsigned char* kimg = smem + (STAGES == 2 ? (j & 1) * STAGE_QK : 0);
         const unsigned char* vimg = kimg + IMG;
         if (valid) {
             const uint4 rt = *reinterpret_cast<const uint4*>(rtab + (phase * 2 + g) * 4);
@@ -275,9 +277,10 @@ __global__ __launch_bounds__(NT, 2) void fwd_kernel(const bf16* __restrict__ qkv
             }
         }
         phase = phase + 1 == nphase ? 0 : phase + 1;
+        if constexpr (STAGES == 1) __syncthreads();      // every wave has finished reading the only stage
         if (j + 1 < ntile) {
-            kst.store(smem + ((j + 1) & 1) * STAGE_QK, tid);
-            vst.store(smem + ((j + 1) & 1) * STAGE_QK + IMG, tid);
+            kst.store(smem + (STAGES == 2 ? ((j + 1) & 1) * STAGE_QK : 0), tid);
+            vst.store(smem + (STAGES == 2 ? ((j + 1) & 1) * STAGE_QK : 0) + IMG, tid);
         }
         __syncthreads();
     };
@@ -660,11 +663,16 @@ int attn2_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t
               float scale, hipStream_t st) {
     using namespace a2;
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
-    const size_t smem = qside_smem(Hp, Wp);
-    static const int pf = [] { const char* v = getenv("PA_ATTN_FWD_PF"); return v ? atoi(v) : 2; }();
-    static bool done1 = false, done2 = false;
-    auto kern = pf == 1 ? fwd_kernel<1> : fwd_kernel<2>;
-    if (int e = set_smem(reinterpret_cast<const void*>(kern), pf == 1 ? done1 : done2)) return e;
+    size_t smem = qside_smem(Hp, Wp);
+    auto smem_bytes_single_stage = [&](size_t& b) { b -= STAGE_QK; if (b < (size_t)NW * IMG) b = (size_t)NW * IMG; };
+    // PA_ATTN_FWD_PF: 0 (default) = single LDS stage, 4 workgroups per CU (measured +12 % over the double-buffered forms: the kernel
+    // is latency/issue-bound and the fourth wave per SIMD buys more than the second barrier costs); 1 = one-tile prefetch,
+    // double-buffered; 2 = two-tile prefetch, double-buffered
+    static const int pf = [] { const char* v = getenv("PA_ATTN_FWD_PF"); return v ? atoi(v) : 0; }();
+    static bool done0 = false, done1 = false, done2 = false;
+    auto kern = pf == 0 ? fwd_kernel<1, 1> : (pf == 1 ? fwd_kernel<1, 2> : fwd_kernel<2, 2>);
+    if (pf == 0) smem_bytes_single_stage(smem);
+    if (int e = set_smem(reinterpret_cast<const void*>(kern), pf == 0 ? done0 : (pf == 1 ? done1 : done2))) return e;
     const int nblk = (L / 32 + NW - 1) / NW;
     PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, out, (size_t)ldo, lse, L, H, Hp,
               Wp, NRP, scale, th_ld(Hp), etab_phases(Wp), nblk, xcd_map_on());
