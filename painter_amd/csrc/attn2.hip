@@ -328,7 +328,8 @@ constexpr int ETAB_BYTES = 32 * 2048;     // up to 32 phases
 DEVI size_t aux_tile_bytes(int Hp, int Wp) { return (size_t)(Hp + Wp) * 128 + 128; }
 
 // =============================================================================================== backward: dQ, bias gradients
-template <int MINW>
+// STAGES as in the forward kernel: one K/V stage brings the LDS footprint under 53 KB, i.e. 3 workgroups per CU (with MINW = 3)
+template <int MINW, int STAGES>
 __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
                                                      const bf16* __restrict__ rcatT, const bf16* __restrict__ dout, size_t lddo,
                                                      const float* __restrict__ lse, const float* __restrict__ delta,
@@ -347,11 +348,11 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     const bool valid = qt * 32 < L;
     const int q = qt * 32 + (lane & 31);
     const int qh = q / Wp, qw = q % Wp;
-    unsigned char* twb = smem + 2 * STAGE_QK + (size_t)row * Wp * 4;
-    unsigned char* thb = smem + 2 * STAGE_QK + ROWS * Wp * 4 + (size_t)row * thld * 2;
+    unsigned char* twb = smem + STAGES * STAGE_QK + (size_t)row * Wp * 4;
+    unsigned char* thb = smem + STAGES * STAGE_QK + ROWS * Wp * 4 + (size_t)row * thld * 2;
     float* tw = reinterpret_cast<float*>(twb);
     bf16* th = reinterpret_cast<bf16*>(thb);
-    uint32_t* rtab = reinterpret_cast<uint32_t*>(smem + 2 * STAGE_QK + ROWS * Wp * 4 + ROWS * thld * 2);
+    uint32_t* rtab = reinterpret_cast<uint32_t*>(smem + STAGES * STAGE_QK + ROWS * Wp * 4 + ROWS * thld * 2);
     // one-hot key patterns of every tile phase, copied once into LDS (a per-tile global load would sit on the critical path)
     unsigned char* etab = reinterpret_cast<unsigned char*>(rtab) + 1024;
     for (int c = tid; c < nphase * 128; c += NT)
@@ -405,7 +406,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             ks.load(kbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
             vs.load(vbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
         }
-        const unsigned char* kimg = smem + (j & 1) * STAGE_QK;
+        const unsigned char* kimg = smem + (STAGES == 2 ? (j & 1) * STAGE_QK : 0);
         const unsigned char* vimg = kimg + IMG;
         const int kh0n = (32 * (j + 1)) / Wp;
         if (valid) {
@@ -463,9 +464,10 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         }
         kh0 = kh0n;
         phase = phase + 1 == nphase ? 0 : phase + 1;
+        if constexpr (STAGES == 1) __syncthreads();      // every wave has finished reading the only stage
         if (j + 1 < ntile) {
-            ks.store(smem + ((j + 1) & 1) * STAGE_QK, tid);
-            vs.store(smem + ((j + 1) & 1) * STAGE_QK + IMG, tid);
+            ks.store(smem + (STAGES == 2 ? ((j + 1) & 1) * STAGE_QK : 0), tid);
+            vs.store(smem + (STAGES == 2 ? ((j + 1) & 1) * STAGE_QK : 0) + IMG, tid);
         }
         __syncthreads();
     }
@@ -504,6 +506,10 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             for (int db = 0; db < 2; ++db)
                 dq[db] = mfma(gfrag(rcatT + (size_t)(db * 32 + (lane & 31)) * NRP, s, g), gf, dq[db]);
         }
+    }
+    // single K/V stage: the staging tiles of waves 2, 3 overlap other waves' bias tables, which the loop above still reads
+    if constexpr (STAGES == 1) __syncthreads();
+    if (valid) {
         stage_rows(stg, dq, 1.f, lane);
         write_rows(stg, dqkv + (size_t)(b * L + qt * 32) * ldq + h * ATT_HD, ldq, lane);
     }
@@ -691,12 +697,15 @@ int attn2_bwd(const bf16* qkv, int64_t ldq, const bf16* rcat, const bf16* rcatT,
     PA_LAUNCH(etab_kernel, dim3(nphase), dim3(256), 0, st, reinterpret_cast<bf16*>(aux), Wp, nphase);
     int e = (int)hipGetLastError();
     if (e) return e;
-    static const int minw = [] { const char* v = getenv("PA_ATTN_BWD_WAVES"); return v ? atoi(v) : 2; }();
+    // PA_ATTN_DQ_WAVES / PA_ATTN_DKV_WAVES: 2 (default) or 3 waves per SIMD; dQ with 3 also uses the single K/V stage
+    static const int dq_w = [] { const char* v = getenv("PA_ATTN_DQ_WAVES"); return v ? atoi(v) : 2; }();
+    static const int minw = [] { const char* v = getenv("PA_ATTN_DKV_WAVES"); return v ? atoi(v) : 2; }();
     {
-        const size_t smem = qside_smem(Hp, Wp) + (size_t)nphase * 2048;
-        auto kern = minw == 3 ? bwd_dq_kernel<3> : bwd_dq_kernel<2>;
+        size_t smem = qside_smem(Hp, Wp) + (size_t)nphase * 2048;
+        if (dq_w == 3) smem -= STAGE_QK;
+        auto kern = dq_w == 3 ? bwd_dq_kernel<3, 1> : bwd_dq_kernel<2, 2>;
         static bool done2 = false, done3 = false;
-        if ((e = set_smem(reinterpret_cast<const void*>(kern), minw == 3 ? done3 : done2))) return e;
+        if ((e = set_smem(reinterpret_cast<const void*>(kern), dq_w == 3 ? done3 : done2))) return e;
         const int nblk = (L / 32 + NW - 1) / NW;
         PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, rcatT, dout, (size_t)lddo,
                   lse, delta, dqkv, dG, reinterpret_cast<unsigned char*>(aux), L, H, Hp, Wp, NRP, scale, th_ld(Hp), nphase, nblk, xcd_map_on());

@@ -11,6 +11,7 @@
 //   kernel B (lane = key, loops over query tiles):
 //       dV = P^T dO,   dK = scale dS^T Q        (bias / lse / Delta come from `aux`, 16-byte reads)
 #include "attn_common.h"
+#include <cstdlib>
 #include "gemm_engine.h"
 #include "../../include/painter_hip.h"
 #include "attn2.h"
@@ -496,7 +497,10 @@ static int relpos_grad_t(const T* dG, const T* qkv, int64_t ldq, float* drcat, f
     OpT<T> A{dG, (size_t)H * NRP, NRP, (size_t)NRP};
     OpT<T> B{qkv, (size_t)ldq, ATT_HD, (size_t)ATT_HD};
     const int nku = (R + TT<T>::BK - 1) / TT<T>::BK;
-    int splits = 32;
+    static const int want = [] { const char* v = getenv("PA_RELPOS_SPLITS"); return v ? atoi(v) : 16; }();      // 16: 45.7 us, 32: 52.6, 8: 67.9 (B=8)
+    int splits = want;
+    if (splits > 32) splits = 32;          // workspace bound (pa_attn_bwd_relpos_workspace_bytes)
+    if (splits < 1) splits = 1;
     if (splits > nku) splits = nku;
     struct Epi {
         float* out; size_t slab; int M, N;
