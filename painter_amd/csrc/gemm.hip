@@ -84,20 +84,34 @@ DEVI void load8(const bf16* p, float4& a, float4& b) {
     a = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
     b = make_float4(bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w));
 }
+struct EpiNone {};
+struct EpiCol8 { float4 a, b; };          // bias[j..j+3], bias[j+4..j+7]
+DEVI EpiCol8 load_col8(const float* bias, int j, int N) {
+    EpiCol8 c{make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if (bias != nullptr && j < N) { c.a = load4(bias + j); c.b = load4(bias + j + 4); }
+    return c;
+}
 template <typename OutT> struct Epi4Bias {
     OutT* out; size_t ldo; const float* bias; int M, N;
-    DEVI void operator()(int i, int j, float4 a, float4 b, int) const {
+    typedef EpiCol8 Col;
+    typedef EpiNone Row;
+    DEVI Col col(int j) const { return load_col8(bias, j, N); }
+    DEVI Row row(int, int) const { return Row{}; }
+    DEVI void store(int i, int j, float4 a, float4 b, const Col& c, const Row&, int) const {
         if (i >= M || j >= N) return;
-        if (bias) { a = add4(a, load4(bias + j)); b = add4(b, load4(bias + j + 4)); }
-        store8(out + (size_t)i * ldo + j, a, b);
+        store8(out + (size_t)i * ldo + j, add4(a, c.a), add4(b, c.b));
     }
 };
 struct Epi4BiasGelu {
     bf16* pre; bf16* act; size_t ld; const float* bias; int M, N;
-    DEVI void operator()(int i, int j, float4 a, float4 b, int) const {
+    typedef EpiCol8 Col;
+    typedef EpiNone Row;
+    DEVI Col col(int j) const { return load_col8(bias, j, N); }
+    DEVI Row row(int, int) const { return Row{}; }
+    DEVI void store(int i, int j, float4 a, float4 b, const Col& c, const Row&, int) const {
         if (i >= M || j >= N) return;
-        a = add4(a, load4(bias + j));
-        b = add4(b, load4(bias + j + 4));
+        a = add4(a, c.a);
+        b = add4(b, c.b);
         const uint4 pk = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
         if (pre) *reinterpret_cast<uint4*>(pre + (size_t)i * ld + j) = pk;
         store8(act + (size_t)i * ld + j,
@@ -107,22 +121,42 @@ struct Epi4BiasGelu {
 };
 struct Epi4BiasResid {
     float* out; const float* resid; size_t ld; const float* bias; const float* rowscale; int rps; int M, N;
-    DEVI void operator()(int i, int j, float4 a, float4 b, int) const {
+    typedef EpiCol8 Col;
+    struct Row { float4 ra, rb; float s; };
+    DEVI Col col(int j) const { return load_col8(bias, j, N); }
+    DEVI Row row(int i, int j) const {
+        Row r{make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), 1.f};
+        if (i < M && j < N) {
+            r.ra = load4(resid + (size_t)i * ld + j);
+            r.rb = load4(resid + (size_t)i * ld + j + 4);
+            if (rowscale) r.s = rowscale[i / rps];
+        }
+        return r;
+    }
+    DEVI void store(int i, int j, float4 a, float4 b, const Col& c, const Row& r, int) const {
         if (i >= M || j >= N) return;
-        const float s = rowscale ? rowscale[i / rps] : 1.f;
-        a = add4(a, load4(bias + j));
-        b = add4(b, load4(bias + j + 4));
-        const float4 ra = load4(resid + (size_t)i * ld + j), rb = load4(resid + (size_t)i * ld + j + 4);
-        store8(out + (size_t)i * ld + j, make_float4(ra.x + s * a.x, ra.y + s * a.y, ra.z + s * a.z, ra.w + s * a.w),
-               make_float4(rb.x + s * b.x, rb.y + s * b.y, rb.z + s * b.z, rb.w + s * b.w));
+        const float s = r.s;
+        a = add4(a, c.a);
+        b = add4(b, c.b);
+        store8(out + (size_t)i * ld + j, make_float4(r.ra.x + s * a.x, r.ra.y + s * a.y, r.ra.z + s * a.z, r.ra.w + s * a.w),
+               make_float4(r.rb.x + s * b.x, r.rb.y + s * b.y, r.rb.z + s * b.z, r.rb.w + s * b.w));
     }
 };
 struct Epi4DGelu {
     bf16* out; const bf16* pre; size_t ld; int M, N;
-    DEVI void operator()(int i, int j, float4 a, float4 b, int) const {
+    typedef EpiNone Col;
+    struct Row { uint4 p; };
+    DEVI Col col(int) const { return Col{}; }
+    DEVI Row row(int i, int j) const {
+        Row r{make_uint4(0, 0, 0, 0)};
+        if (i < M && j < N) r.p = *reinterpret_cast<const uint4*>(pre + (size_t)i * ld + j);
+        return r;
+    }
+    DEVI void store(int i, int j, float4 a, float4 b, const Col&, const Row& r, int) const {
         if (i >= M || j >= N) return;
-        float4 pa, pb;
-        load8(pre + (size_t)i * ld + j, pa, pb);
+        const uint4 w = r.p;
+        const float4 pa = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+        const float4 pb = make_float4(bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w));
         store8(out + (size_t)i * ld + j,
                make_float4(a.x * gelu_grad_fast(pa.x), a.y * gelu_grad_fast(pa.y), a.z * gelu_grad_fast(pa.z), a.w * gelu_grad_fast(pa.w)),
                make_float4(b.x * gelu_grad_fast(pb.x), b.y * gelu_grad_fast(pb.y), b.z * gelu_grad_fast(pb.z), b.w * gelu_grad_fast(pb.w)));
@@ -130,18 +164,26 @@ struct Epi4DGelu {
 };
 struct Epi4PixShuf {
     bf16* out; const float* bias; int Hp, Wp, P, C, M, N;
-    DEVI void operator()(int i, int j, float4 a, float4 b, int) const {
+    typedef EpiCol8 Col;
+    typedef EpiNone Row;
+    DEVI Col col(int j) const { return load_col8(bias, j, N); }
+    DEVI Row row(int, int) const { return Row{}; }
+    DEVI void store(int i, int j, float4 a, float4 b, const Col& cc, const Row&, int) const {
         if (i >= M || j >= N) return;
         const int L = Hp * Wp;
         const int bb = i / L, l = i - bb * L, h = l / Wp, w = l - h * Wp;
         const int c = j % C, pq = j / C, q = pq % P, p = pq / P;
         const size_t y = (size_t)bb * Hp * P + h * P + p, x = (size_t)w * P + q;
-        store8(out + (y * (size_t)(Wp * P) + x) * C + c, add4(a, load4(bias + j)), add4(b, load4(bias + j + 4)));
+        store8(out + (y * (size_t)(Wp * P) + x) * C + c, add4(a, cc.a), add4(b, cc.b));
     }
 };
 struct Epi4Slab {
     float* out; size_t ldo; size_t slab; int M, N;
-    DEVI void operator()(int i, int j, float4 a, float4 b, int split) const {
+    typedef EpiNone Col;
+    typedef EpiNone Row;
+    DEVI Col col(int) const { return Col{}; }
+    DEVI Row row(int, int) const { return Row{}; }
+    DEVI void store(int i, int j, float4 a, float4 b, const Col&, const Row&, int split) const {
         if (i >= M || j >= N) return;
         store8(out + (size_t)split * slab + (size_t)i * ldo + j, a, b);
     }

@@ -112,8 +112,10 @@ template <> struct Frag4<true> {
     }
 };
 
-// Epilogue contract: epi(i, j, lo, hi, split) with j a multiple of 8, lo = D[i][j..j+3], hi = D[i][j+4..j+7]; the functor
-// bounds-checks (N % 8 == 0 is required by ok()).
+// Epilogue contract (j a multiple of 8; N % 8 == 0 is required by ok(); the functor bounds-checks):
+//   Col col(j)                      per-lane column constants (bias[j..j+7]), loaded once per tile
+//   Row row(i, j)                   per-(row, 8 columns) global inputs (residual, GELU pre-activation), loaded ahead of the stores
+//   store(i, j, lo, hi, col, row, split)   lo = D[i][j..j+3], hi = D[i][j+4..j+7]
 template <bool AMM, bool BMM, class Epi>
 __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag, uint32_t lda, const bf16* __restrict__ Bg,
                                                       uint32_t ldb, Epi epi, int M, int N, int ktiles, int ktiles_per_split,
@@ -282,27 +284,45 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
     // store instruction (measured: the store tail cost ~1/3 of a K=1024 tile).  Instead every wave passes its tile, one
     // 32 x 64 block at a time, through a private LDS scratch ([32][68] floats, padded: conflict-free ds_write_b128) and
     // re-reads it 8 columns per lane, 8 lanes per row, so the fused epilogue stores whole 128/256-byte row segments.
+    // Global LOADS of the epilogue (bias, residual, GELU pre-activation) are issued ahead of the stores they feed: a load
+    // placed after a store can only be waited for with vmcnt(0), i.e. together with every store still in flight (stores and
+    // loads share the counter), which made each of the 16 row groups pay a full store round trip (rocprof: 11-13 us of a
+    // 41 us fc1 tile).  col() is loaded once per tile, row() for two 32-row blocks at a time before that half's stores.
     bar();                 // every wave's DMAs have landed and nobody reads the staging units any more
     {
         float* stg = reinterpret_cast<float*>(smem + wv * 8704);
         const int lr = lane & 31, g = lane >> 5, rrow = lane >> 3, c0 = (lane & 7) * 8;
+        const int jcol = j0 + wc * 64 + c0;
+        const typename Epi::Col col = epi.col(jcol);
 #pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {
+        for (int half = 0; half < 2; ++half) {
+            typename Epi::Row rows[2][4];
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x16& c = acc[mb][nb];
-                    *reinterpret_cast<float4*>(stg + lr * 68 + nb * 32 + q * 8 + g * 4) =
-                        make_float4(c[q * 4 + 0], c[q * 4 + 1], c[q * 4 + 2], c[q * 4 + 3]);
+                for (int st = 0; st < 4; ++st) {
+                    const int mb = half * 2 + m2;
+                    rows[m2][st] = epi.row(i0 + wr * 128 + (mb >> 1) * 64 + (mb & 1) * 32 + st * 8 + rrow, jcol);
                 }
-            const int ib = i0 + wr * 128 + (mb >> 1) * 64 + (mb & 1) * 32;
 #pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int r = st * 8 + rrow;
-                const float4 lo = *reinterpret_cast<const float4*>(stg + r * 68 + c0);
-                const float4 hi = *reinterpret_cast<const float4*>(stg + r * 68 + c0 + 4);
-                epi(ib + r, j0 + wc * 64 + c0, lo, hi, split);
+            for (int m2 = 0; m2 < 2; ++m2) {
+                const int mb = half * 2 + m2;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x16& c = acc[mb][nb];
+                        *reinterpret_cast<float4*>(stg + lr * 68 + nb * 32 + q * 8 + g * 4) =
+                            make_float4(c[q * 4 + 0], c[q * 4 + 1], c[q * 4 + 2], c[q * 4 + 3]);
+                    }
+                const int ib = i0 + wr * 128 + (mb >> 1) * 64 + (mb & 1) * 32;
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    const int r = st * 8 + rrow;
+                    const float4 lo = *reinterpret_cast<const float4*>(stg + r * 68 + c0);
+                    const float4 hi = *reinterpret_cast<const float4*>(stg + r * 68 + c0 + 4);
+                    epi.store(ib + r, jcol, lo, hi, col, rows[m2][st], split);
+                }
             }
         }
     }
