@@ -171,6 +171,7 @@ int pa_patchify(const float* img, float* out, int batch, int Hp, int Wp, int P, 
  * g == NULL marks a parameter without gradient (skipped).  All tensors fp32, contiguous. */
 typedef struct PaOptTensor {
     void* p; const void* g; void* m; void* v;    /* parameter, gradient, exp_avg, exp_avg_sq */
+    void* w16;                                   /* optional bf16 copy of p refreshed by pa_adamw_step, or NULL */
     int64_t n;                                   /* elements */
     int32_t group;                               /* index into PaOptGroups */
     int32_t first_chunk;

@@ -6,6 +6,8 @@
 //   pa_grad_sumsq   one read of every gradient: per-chunk sums of squares (+ a non-finite count), reduced in a fixed order
 //   pa_adamw_step   one read-modify-write of p, m, v: unscale, clip coefficient and the inf/nan skip are applied on the fly
 //                   from the device-side result of pass 1 -- no host synchronisation anywhere.
+// Pass 2 can also refresh a bf16 copy of the parameter (the GEMM operand cache of the engine) in the same sweep, which removes the
+// per-step fp32 -> bf16 cast pass over the weight matrices (2.2 GB of traffic).
 // Both are pure HBM streaming kernels (16-byte accesses, one 256-thread workgroup per 8192-element chunk; a chunk never
 // straddles two tensors).  Algorithmic bytes: pass 1 = 4 B/element, pass 2 = 28 B/element (read p, g, m, v; write p, m, v).
 #include "common.h"
@@ -21,6 +23,7 @@ struct TensorRec {                        // one per parameter tensor (device ta
     const float* g;
     float* m;
     float* v;
+    bf16* w16;                            // optional bf16 copy of the parameter kept in step with it (GEMM operand cache), or NULL
     int64_t n;
     int32_t group;
     int32_t first_chunk;                  // index of this tensor's first chunk in the flat chunk order
@@ -131,7 +134,9 @@ __global__ __launch_bounds__(OPT_NT) void adamw_step_kernel(const TensorRec* __r
     float* m = r.m + base;
     float* v = r.v + base;
     const float* g = r.g + base;
-    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(g)) & 15) == 0;
+    bf16* w16 = r.w16 ? r.w16 + base : nullptr;
+    const bool al = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v) | reinterpret_cast<uintptr_t>(g) |
+                      (reinterpret_cast<uintptr_t>(w16) << 1)) & 15) == 0;
     if (al) {
         for (int i = threadIdx.x * 4; i + 3 < len; i += OPT_NT * 4) {
             float4 pp = *reinterpret_cast<const float4*>(p + i), mm = *reinterpret_cast<const float4*>(m + i),
@@ -144,10 +149,17 @@ __global__ __launch_bounds__(OPT_NT) void adamw_step_kernel(const TensorRec* __r
             *reinterpret_cast<float4*>(p + i) = pp;
             *reinterpret_cast<float4*>(m + i) = mm;
             *reinterpret_cast<float4*>(v + i) = vv;
+            if (w16) *reinterpret_cast<uint2*>(w16 + i) = make_uint2(pack_bf16x2(pp.x, pp.y), pack_bf16x2(pp.z, pp.w));
         }
-        for (int i = (len & ~3) + threadIdx.x; i < len; i += OPT_NT) adamw1(p[i], m[i], v[i], g[i] * gmul, lr, wd, b1, b2, eps, step_size, rsqrt_bc2);
+        for (int i = (len & ~3) + threadIdx.x; i < len; i += OPT_NT) {
+            adamw1(p[i], m[i], v[i], g[i] * gmul, lr, wd, b1, b2, eps, step_size, rsqrt_bc2);
+            if (w16) w16[i] = (bf16)p[i];
+        }
     } else {
-        for (int i = threadIdx.x; i < len; i += OPT_NT) adamw1(p[i], m[i], v[i], g[i] * gmul, lr, wd, b1, b2, eps, step_size, rsqrt_bc2);
+        for (int i = threadIdx.x; i < len; i += OPT_NT) {
+            adamw1(p[i], m[i], v[i], g[i] * gmul, lr, wd, b1, b2, eps, step_size, rsqrt_bc2);
+            if (w16) w16[i] = (bf16)p[i];
+        }
     }
 }
 

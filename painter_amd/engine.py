@@ -107,6 +107,18 @@ class HotPath:
             return buf
         return ent[1]
 
+    def shadow_buffers(self):
+        """{parameter data_ptr: cached bf16 copy} -- lets painter_amd.optim.AdamW refresh the copies inside its update pass."""
+        return {key[1]: ent[1] for key, ent in self._wcache.items()}
+
+    def mark_fresh(self, params):
+        """The optimizer has rewritten these parameters AND their bf16 copies: adopt the new versions."""
+        by_ptr = {p.data_ptr(): p for p in params}
+        for key, ent in list(self._wcache.items()):
+            p = by_ptr.get(key[1])
+            if p is not None:
+                self._wcache[key] = (p._version, ent[1])
+
     # ------------------------------------------------------------------ forward
     def forward(self, P, imgs, tgts, mask_u8, valid, seg_type=None, merge_between_batch=-1, drop_scales=None, need_grad=True):
         c, T = self.cfg, self.T

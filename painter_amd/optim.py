@@ -23,7 +23,7 @@ import torch
 from . import ops
 from ._lib import check, lib
 
-_REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("group", "<i4"), ("first_chunk", "<i4")])
+_REC = np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("w16", "<u8"), ("n", "<i8"), ("group", "<i4"), ("first_chunk", "<i4")])
 MAX_GROUPS = 64
 
 
@@ -50,6 +50,13 @@ class AdamW(torch.optim.Optimizer):
         self._cached = None
         self._tab_dev = None
         self._steps = None                   # device float32 [64]: per-group step counts (a skipped step must not advance them)
+        self._model = None
+
+    def bind_model(self, model):
+        """Let the update refresh the model's cached bf16 weight copies in the same pass (saves the per-step cast kernels).
+        `model` is a painter_amd Painter / SegGPT module; optional."""
+        self._model = model
+        return self
 
     # ------------------------------------------------------------------ state / table
     def _steps_for(self, device):
@@ -85,6 +92,10 @@ class AdamW(torch.optim.Optimizer):
         chunk = int(lib.pa_opt_chunk_elems())
         recs, dev = [], None
         nchunks = 0
+        self._fresh = []
+        shadows = None
+        if self._model is not None and getattr(self._model, "_hot", None) is not None:
+            shadows = self._model._hot.shadow_buffers()
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
                 if not p.requires_grad:
@@ -100,7 +111,13 @@ class AdamW(torch.optim.Optimizer):
                         raise RuntimeError("painter_amd.optim.AdamW: gradients must be dense contiguous fp32")
                     gptr = g.data_ptr()
                 n = p.numel()
-                recs.append((p.data_ptr(), gptr, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n, gi, nchunks))
+                w16 = 0
+                if shadows is not None and gptr:
+                    buf = shadows.get(p.data_ptr())
+                    if buf is not None and buf.numel() == n:
+                        w16 = buf.data_ptr()
+                        self._fresh.append(p)
+                recs.append((p.data_ptr(), gptr, st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), w16, n, gi, nchunks))
                 nchunks += (n + chunk - 1) // chunk
         if not recs:
             return None, 0, 0, None
@@ -160,6 +177,11 @@ class AdamW(torch.optim.Optimizer):
         check(lib.pa_adamw_step(tab.data_ptr(), nt, nchunks, ctypes.byref(gs), float(b1), float(b2), float(eps),
                                 self._steps_for(dev).data_ptr(), f32(norm_info), f32(grad_scale), f32(found_inf),
                                 float(max_norm) if max_norm else 0.0, ops.stream()), "pa_adamw_step")
+        # the kernel rewrote the parameters behind autograd's back: bump their version counters so that everything keyed on
+        # them (the engine's cached bf16 operand copies, autograd's saved-tensor checks) sees the update
+        torch.autograd.graph.increment_version([p for g in self.param_groups for p in g["params"] if p.requires_grad and p.grad is not None])
+        if self._model is not None and self._fresh:
+            self._model._hot.mark_fresh(self._fresh)     # parameter and bf16 copy were rewritten together (or, on a skip, neither)
         return loss
 
 

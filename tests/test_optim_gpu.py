@@ -76,7 +76,7 @@ def test_torch_gradscaler_drives_fused_adamw_and_state_dict_roundtrip():
     ref_p = [torch.nn.Parameter(p.clone().cuda()) for p in params]
     groups = lambda ps: [{"params": [p], "lr": lr, "weight_decay": wd} for p, (lr, wd) in zip(ps, cfg)]
     opt, ref = PO.AdamW(groups(dev_p), lr=1e-3, betas=(0.9, 0.95)), torch.optim.AdamW(groups(ref_p), lr=1e-3, betas=(0.9, 0.95))
-    s1, s2 = torch.cuda.amp.GradScaler(init_scale=256.0), torch.cuda.amp.GradScaler(init_scale=256.0)
+    s1, s2 = torch.amp.GradScaler("cuda", init_scale=256.0), torch.amp.GradScaler("cuda", init_scale=256.0)
     ws = [torch.randn(s, generator=g).cuda() for s in SHAPES]
     for it in range(2):
         for ps, o, sc in ((dev_p, opt, s1), (ref_p, ref, s2)):
@@ -99,3 +99,40 @@ def test_torch_gradscaler_drives_fused_adamw_and_state_dict_roundtrip():
         o.step()
     for a, b in zip(dev_p, ref_p):
         assert torch.allclose(a.detach(), b.detach(), rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("bind", [False, True])
+def test_fused_step_invalidates_the_engines_bf16_weight_cache(bind):
+    """The model keeps bf16 copies of its weight matrices keyed on the parameter version: after a fused step (which rewrites the
+    parameters from a HIP kernel) the next forward must use the new weights -- same loss as a fresh model holding them."""
+    from functools import partial
+
+    import torch.nn as nn
+
+    from oracle import painter_oracle as O
+    from painter_amd import models_painter
+    cfg = O.small_config()
+
+    def make():
+        m = models_painter.Painter(img_size=cfg.img_size, patch_size=16, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+                                   drop_path_rate=0.0, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6), use_rel_pos=True,
+                                   decoder_embed_dim=cfg.decoder_embed_dim, compute_dtype="bf16")
+        m.load_state_dict(O.random_params(cfg, 7), strict=True)
+        return m.cuda().eval()
+
+    imgs, tgts, mask, valid = O.synthetic_batch(cfg, 2, 8, "random")
+    args = (imgs.cuda(), tgts.cuda())
+    kw = lambda: dict(bool_masked_pos=mask.cuda(), valid=valid.clone().cuda())
+    m = make()
+    opt = PO.AdamW(m.parameters(), lr=1e-2, weight_decay=0.0)
+    if bind:
+        opt.bind_model(m)                               # the update pass also rewrites the cached bf16 copies
+    loss0, _, _ = m(*args, **kw())
+    loss0.backward()
+    opt.step()
+    loss1, _, _ = m(*args, **kw())                      # must see the updated weights
+    m2 = make()
+    m2.load_state_dict(m.state_dict())
+    loss2, _, _ = m2(*args, **kw())
+    assert abs(loss1.item() - loss2.item()) <= 1e-6 * abs(loss2.item()), (loss0.item(), loss1.item(), loss2.item())
+    assert abs(loss1.item() - loss0.item()) > 1e-4 * abs(loss0.item())          # and the step did change something

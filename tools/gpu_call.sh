@@ -2,7 +2,4 @@
 mkdir -p gpurun_out
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_kernels_gpu.py -q -m gpu -p no:cacheprovider -x -k "gemm256 or linear" 2>&1 | tail -4
-timeout 300 python tools/gemm_probe.py 2>&1 | grep -v amdgpu
-timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench.log 2>&1
-grep metric gpurun_out/bench.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['avg_us'])"
+timeout 600 python -m pytest tests/test_optim_gpu.py -q -m gpu -p no:cacheprovider --tb=short 2>&1 | tail -12
