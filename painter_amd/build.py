@@ -12,7 +12,15 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libpainter_hip.so")
 ARCH = "gfx950"
+# -fno-slp-vectorize: hipcc (ROCm 7.2) SLP-packs adjacent fp32 adds / muls / fmas into v_pk_*_f32.  On gfx950 a kernel built that
+# way (LayerNorm backward: the packed (s1, s2) row-sum accumulators) returned a wrong s2 for one row in ~1 % of its launches whenever
+# MFMA workgroups of ANOTHER kernel were resident on the same CU (second HIP stream; tools/race_iso.py reproduces it in isolation,
+# 32 / 3600 launches, 0 / 3600 without the flag), which made the two-stream backward non-deterministic.  Without SLP packing the
+# whole step is bit-stable in every probe and not slower (125.7 vs 126.4 images/s).  PA_SLP=1 re-enables it for experiments.
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
+if os.environ.get("PA_SLP") != "1":
+    FLAGS = FLAGS + ["-fno-slp-vectorize"]
+EXTRA = {}
 
 
 def _hipcc():
@@ -44,10 +52,11 @@ def headers():
 def _compile(src, stamp):
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
     tag = obj + ".stamp"
-    want = _digest([src] + headers())
+    extra = EXTRA.get(os.path.basename(src), [])
+    want = _digest([src] + headers()) + "|" + " ".join(extra) + "|" + " ".join(FLAGS)
     if not stamp and os.path.exists(obj) and os.path.exists(tag) and open(tag).read() == want:
         return obj, False
-    cmd = [_hipcc()] + FLAGS + ["-c", src, "-o", obj]
+    cmd = [_hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed for %s:\n%s" % (src, r.stderr[-4000:]))

@@ -27,8 +27,7 @@ template <typename T> __global__ void attn_delta_kernel(const T* o, size_t ldo, 
         float s = 0.f;
 #pragma unroll
         for (int e = 0; e < 16; ++e) s += to_f(o[(size_t)row * ldo + c + e]) * to_f(d_o[(size_t)row * lddo + c + e]);
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
+        s = quad_sum(s);
         if ((lane & 3) == 0) delta[((size_t)b * H + c / ATT_HD) * L + l] = s;
     }
 }

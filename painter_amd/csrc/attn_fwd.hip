@@ -91,7 +91,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
                 p[rg * 4 + 3] = fmaf(sacc[rg * 4 + 3], sl, bhv + bw.w);
                 tmax = fmaxf(tmax, fmaxf(fmaxf(p[rg * 4], p[rg * 4 + 1]), fmaxf(p[rg * 4 + 2], p[rg * 4 + 3])));
             }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            tmax = fmaxf(tmax, lane_xor32(tmax));
             const float mn = fmaxf(m, tmax);
             const float alpha = __builtin_amdgcn_exp2f(m - mn);
             float rs = 0.f;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
     unsigned char* stg = smem + 4 * KVB + (size_t)wave * tab_stride;
     constexpr int ROWB = ATT_HD * sizeof(T);
     if (valid) {
-        const float lt = l + __shfl_xor(l, 32, 64);
+        const float lt = l + lane_xor32(l);
         const float inv = 1.f / lt;
         if (g == 0) lse[(size_t)bh * L + q] = (m + __builtin_amdgcn_logf(lt)) * LN2_F;   // v_log_f32 = log2
 #pragma unroll

@@ -80,14 +80,35 @@ DEVI int lds256(int row, int slot) { return row * 256 + ((slot ^ (row & 15)) << 
 DEVI int lds64(int row, int gran) { return row * 64 + ((gran ^ ((row >> 2) & 7)) << 3); }     // 8 granules of 8 B
 
 // ---------------------------------------------------------------------------------------------
-DEVI float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Cross-lane exchanges on the VALU only (DPP within a row of 16 lanes, gfx950's v_permlane16_swap / v_permlane32_swap across rows).
+// hipcc lowers __shfl_xor to ds_bpermute_b32, i.e. through the LDS unit; with a second kernel's workgroups resident on the same
+// CU (two streams, RCCL) a LayerNorm-backward row sum built from ds_bpermute came back wrong about once in 100 launches
+// (tools/race_iso.py: exactly one row of dx off by its c2 term).  These forms never leave the SIMD.
+template <int CTRL> DEVI float lane_dpp(float v) {
+    const int i = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false));
 }
+DEVI float lane_xor1(float v) { return lane_dpp<0xB1>(v); }     // quad_perm [1,0,3,2]
+DEVI float lane_xor2(float v) { return lane_dpp<0x4E>(v); }     // quad_perm [2,3,0,1]
+DEVI float lane_xor16(float v) {                                 // value of lane ^ 16
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 16) ? r[0] : r[1]);
+}
+DEVI float lane_xor32(float v) {                                 // value of lane ^ 32
+    const uint32_t u = __builtin_bit_cast(uint32_t, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
+}
+// sum / max over the 4 lanes of a quad, the 16 lanes of a row, the whole wave; every lane gets the result.  After the two quad steps
+// all lanes of a quad agree, so the mirror permutations (lane i <-> 7-i in a half row, i <-> 15-i in a row) pair distinct groups.
+DEVI float quad_sum(float v) { v += lane_xor1(v); v += lane_xor2(v); return v; }
+DEVI float row16_sum(float v) { v = quad_sum(v); v += lane_dpp<0x141>(v); v += lane_dpp<0x140>(v); return v; }
+DEVI float wave_sum(float v) { v = row16_sum(v); v += lane_xor16(v); v += lane_xor32(v); return v; }
 DEVI float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    v = fmaxf(v, lane_xor1(v)); v = fmaxf(v, lane_xor2(v));
+    v = fmaxf(v, lane_dpp<0x141>(v)); v = fmaxf(v, lane_dpp<0x140>(v));
+    v = fmaxf(v, lane_xor16(v)); v = fmaxf(v, lane_xor32(v));
     return v;
 }
 

@@ -208,12 +208,12 @@ template <typename T, bool FAST = false> struct EpiTail {
                     }
                     s += (y[o] + y[o + 1]) + (y[o + 2] + y[o + 3]);
                 }
-            s += __shfl_xor(s, 32, 64);
+            s += lane_xor32(s);
             const float mu = s * (1.f / CV_C);
             float q = 0.f;
 #pragma unroll
             for (int e = 0; e < 32; ++e) { const float d = y[e] - mu; q += d * d; }
-            q += __shfl_xor(q, 32, 64);
+            q += lane_xor32(q);
             const float rs = 1.f / sqrtf(q * (1.f / CV_C) + eps);
             float o0 = 0.f, o1 = 0.f, o2 = 0.f;
 #pragma unroll
@@ -232,9 +232,9 @@ template <typename T, bool FAST = false> struct EpiTail {
                     o1 += (a0 * wb.x + a1 * wb.y) + (a2 * wb.z + a3 * wb.w);
                     o2 += (a0 * wc.x + a1 * wc.y) + (a2 * wc.z + a3 * wc.w);
                 }
-            o0 += __shfl_xor(o0, 32, 64);
-            o1 += __shfl_xor(o1, 32, 64);
-            o2 += __shfl_xor(o2, 32, 64);
+            o0 += lane_xor32(o0);
+            o1 += lane_xor32(o1);
+            o2 += lane_xor32(o2);
             if (pix < N && g == 0) {
                 const int b = pix / HW, rem = pix % HW;
                 float* pp = pred + (size_t)b * 3 * HW + rem;

@@ -354,14 +354,12 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__
         if constexpr (sizeof(T) == 2) { y[0] = bf16_lo(raw.x); y[1] = bf16_hi(raw.x); y[2] = bf16_lo(raw.y); y[3] = bf16_hi(raw.y); }
         else { y[0] = __builtin_bit_cast(float, raw.x); y[1] = __builtin_bit_cast(float, raw.y); y[2] = __builtin_bit_cast(float, raw.z); y[3] = __builtin_bit_cast(float, raw.w); }
         float s = (y[0] + y[1]) + (y[2] + y[3]);
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) s += __shfl_xor(s, o, 64);
+        s = row16_sum(s);
         const float mu = s * (1.f / 64);
         float q = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) q += (y[e] - mu) * (y[e] - mu);
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
+        q = row16_sum(q);
         const float rs = 1.f / sqrtf(q * (1.f / 64) + eps);
         const int b = pix / HW, rem = pix % HW;
         const float* dp = dpred + (size_t)b * 3 * HW + rem;
@@ -391,8 +389,8 @@ __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__
             m2 += dxh[e] * xh[e];
         }
         if (sub == 0) { ab1[0] += d0; ab1[1] += d1; ab1[2] += d2; }
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { m1 += __shfl_xor(m1, o, 64); m2 += __shfl_xor(m2, o, 64); }
+        m1 = row16_sum(m1);
+        m2 = row16_sum(m2);
         m1 *= (1.f / 64); m2 *= (1.f / 64);
         float r[4];
 #pragma unroll

@@ -20,6 +20,13 @@ from . import hostmath, ops
 from ._lib import EPI_BIAS, EPI_BIAS_F32, EPI_BIAS_RESID
 
 
+# diagnostics for the two-stream backward: keep every tensor the side stream reads alive until the end of the backward (no
+# allocator reuse), or serialise the two streams (no concurrency)
+_DBG_KEEP = os.environ.get("PAINTER_AMD_DEBUG_KEEPALIVE", "0") == "1"
+_DBG_SERIAL = os.environ.get("PAINTER_AMD_DEBUG_SERIAL", "0") == "1"
+_DBG_TRACE = os.environ.get("PAINTER_AMD_DEBUG_TRACE", "0") == "1"     # checksums of the backward's intermediates -> HotPath.trace
+
+
 class HotPathConfig:
     def __init__(self, img_size, patch_size, embed_dim, depth, num_heads, mlp_ratio, decoder_embed_dim,
                  pretrain_img_size, pretrain_use_cls_token, use_rel_pos, ln_eps, loss_func, seggpt, drop_path_rate):
@@ -75,8 +82,10 @@ class HotPath:
         self._M = None
         self._wcache = {}
         self._side = {}
-        # parameter-gradient kernels (dW = dY^T.X, bias column sums) are off the backward's critical path: they go to a second
-        # HIP stream so that the chip fills the CUs the dgrad/LayerNorm kernels of the main stream leave idle (section 6)
+        # parameter-gradient kernels (dW = dY^T.X, bias column sums) are off the backward's critical path: they go to a second HIP
+        # stream (+3.5 % at B=8; PAINTER_AMD_SIDE_STREAM=0 turns it off).  This mode exposed two things, both fixed: a cross-stream
+        # allocator hazard on the gradient buckets, and SLP-packed fp32 VALU code mis-computing beside another kernel's MFMA
+        # workgroups (build.py: -fno-slp-vectorize); DESIGN.md section 6.
         self.use_side_stream = os.environ.get("PAINTER_AMD_SIDE_STREAM", "1") != "0"
 
     def side_stream(self, device):
@@ -200,19 +209,38 @@ class HotPath:
         G = {}
         main = torch.cuda.current_stream(dev)
         side = self.side_stream(dev) if self.use_side_stream else None
+        keep = []
+        self.trace = []
+
+        def tr(name, t):
+            if _DBG_TRACE:
+                self.trace.append((name, t.detach().double().abs().sum()))
+
+        filt = getattr(self, "side_filter", None)          # diagnostics: {"dec","fc2","fc1","proj","qkv"} subsets, "nocolsum", "nowgrad"
 
         def param_grads(wname, bname, dy, x):
             """G[wname] = dy^T.x, G[bname] = colsum(dy) -- on the side stream when enabled."""
-            if side is None:
+            tag = "dec" if wname.startswith("decoder") else wname.split(".")[-2]
+            if side is None or (filt is not None and tag not in filt):
                 G[wname] = ops.linear_wgrad(dy, x)
                 G[bname] = ops.colsum(dy)
                 return
+            if filt is not None and "nocolsum" in filt:
+                G[bname] = ops.colsum(dy)
+            if filt is not None and "nowgrad" in filt:
+                G[wname] = ops.linear_wgrad(dy, x)
             side.wait_stream(main)                 # dy (and x) are enqueued on main
             with torch.cuda.stream(side):
-                G[wname] = ops.linear_wgrad(dy, x)
-                G[bname] = ops.colsum(dy)
+                if wname not in G:
+                    G[wname] = ops.linear_wgrad(dy, x)
+                if bname not in G:
+                    G[bname] = ops.colsum(dy)
             dy.record_stream(side)                 # the allocator must not hand these out again before the side stream is done
             x.record_stream(side)
+            if _DBG_KEEP:
+                keep.extend([dy, x])
+            if _DBG_SERIAL:
+                main.wait_stream(side)
 
         def ready(names):
             if sync is None:
@@ -240,6 +268,7 @@ class HotPath:
         del dy3
         param_grads("decoder_embed.weight", "decoder_embed.bias", dE, S.concat)
         dconcat = ops.linear_dgrad(dE, self.w("decoder_embed.weight", P))
+        tr("dE", dE); tr("dconcat", dconcat)
         del dE
         ready(["decoder_embed.weight", "decoder_embed.bias"])
         ready([n for n in G if n.startswith("decoder_pred.")])
@@ -267,22 +296,28 @@ class HotPath:
                 dyT = dyT_next
             # ---- MLP branch: x2 = x1 + s_m * fc2(gelu(fc1(LN2(x1))))
             param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dyT, act)
+            tr("%d.dyT" % i, dyT)
             dpre = ops.linear_dgrad(dyT, self.w(pre + "mlp.fc2.weight", P), pre=hpre)
+            tr("%d.dpre" % i, dpre)
             param_grads(pre + "mlp.fc1.weight", pre + "mlp.fc1.bias", dpre, ln2)
             dln2 = ops.linear_dgrad(dpre, self.w(pre + "mlp.fc1.weight", P))
+            tr("%d.dln2" % i, dln2)
             del dpre
             # dyT may still be read by the side stream: the attention branch's dY gets its own buffer
             dyA = torch.empty_like(dyT) if side is not None else dyT
             dx, gb = ops.layernorm_bwd(dln2, x1, mean2, rstd2, P[pre + "norm2.weight"], dres=dx, dx=dx, dxT=dyA,
                                        rowscale=ds_a, rows_per_sample=L)
             del dyT
+            tr("%d.dx_ln2" % i, dx); tr("%d.dyA" % i, dyA); tr("%d.gb2" % i, gb)
             G[pre + "norm2.weight"], G[pre + "norm2.bias"] = gb[0], gb[1]
             # ---- attention branch: x1 = x0 + s_a * proj(attn(LN1(x0)))
             param_grads(pre + "attn.proj.weight", pre + "attn.proj.bias", dyA, ao)
             dao = ops.linear_dgrad(dyA, self.w(pre + "attn.proj.weight", P), out=dln2)
+            tr("%d.dao" % i, dao)
             del dyA
             rcatT = ops.relpos_pack_t(P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], c.Hp, c.Wp, T)
             dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, ao, dao, lse, Bc, L, c.heads, c.Hp, c.Wp, c.scale)
+            tr("%d.dqkv" % i, dqkv); tr("%d.drcat" % i, drcat)
             nh, nw = 2 * c.Hp - 1, 2 * c.Wp - 1
             G[pre + "attn.rel_pos_h"] = drcat[:nh]
             G[pre + "attn.rel_pos_w"] = drcat[nh:nh + nw]
@@ -297,6 +332,7 @@ class HotPath:
             dx, gb = ops.layernorm_bwd(dln1, x0, mean1, rstd1, P[pre + "norm1.weight"], dres=dx, dx=dx, dxT=dyT_next,
                                        rowscale=ds_next if dyT_next is not None else None, rows_per_sample=L)
             G[pre + "norm1.weight"], G[pre + "norm1.bias"] = gb[0], gb[1]
+            tr("%d.dx_ln1" % i, dx)
             del x0, ln1, qkv, ao, x1, ln2, hpre, act
             ready([n for n in G if n.startswith(pre)])
         G["norm.weight"], G["norm.bias"] = dnorm[0], dnorm[1]
@@ -314,6 +350,9 @@ class HotPath:
                "segment_token_x", "segment_token_y", "mask_token"])
         if side is not None:
             main.wait_stream(side)                 # every gradient is ordered before whatever the caller enqueues next
+        if keep:
+            torch.cuda.synchronize()
+            keep.clear()
         if sync is not None:
             sync.finish()
         return G

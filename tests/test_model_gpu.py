@@ -182,3 +182,34 @@ def test_ddp_gradient_path_single_rank_rccl():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "ddp_selftest.py")], cwd=root, env=env, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "DDP selftest OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_three_training_steps_match_cpu_reference_loop():
+    """End to end: forward + hand-written backward (fp32 build) + fused AdamW with global-norm clipping, three steps, against the
+    same loop on the CPU oracle (autograd of oracle.painter_oracle.forward + torch.optim.AdamW + clip_grad_norm_)."""
+    from painter_amd import optim as PO
+    cfg = O.small_config()
+    m, P = build(cfg, 13, "fp32")
+    names = [n for n, _ in m.named_parameters()]
+    groups = lambda params: [{"params": [p for n, p in params if p.ndim > 1], "weight_decay": 0.05},
+                             {"params": [p for n, p in params if p.ndim <= 1], "weight_decay": 0.0}]
+    # eps = 1e-3: with the default 1e-8 the normalised update of an element whose gradient is ~0 is decided by rounding noise
+    # (sign flips worth 2 lr), which would test the noise, not the path
+    opt = PO.AdamW(groups(list(m.named_parameters())), lr=2e-3, betas=(0.9, 0.95), eps=1e-3).bind_model(m)
+    Pc = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    ref = torch.optim.AdamW(groups([(n, Pc[n]) for n in names]), lr=2e-3, betas=(0.9, 0.95), eps=1e-3)
+    for it in range(3):
+        imgs, tgts, mask, valid = O.synthetic_batch(cfg, 2, 40 + it, "random")
+        opt.zero_grad()
+        loss, _, _ = m(imgs.cuda(), tgts.cuda(), bool_masked_pos=mask.reshape(2, *cfg.grid).cuda(), valid=valid.clone().cuda())
+        loss.backward()
+        opt.grad_sumsq()
+        opt.step(max_norm=3.0)
+        ref.zero_grad()
+        lo, _, _ = O.forward(Pc, cfg, imgs, tgts, mask, valid.clone())
+        lo.backward()
+        torch.nn.utils.clip_grad_norm_([Pc[n] for n in names], 3.0)
+        ref.step()
+        assert abs(loss.item() - lo.item()) <= 2e-4 * abs(lo.item()), (it, loss.item(), lo.item())
+    worst = max(float((p.detach().cpu() - Pc[n].detach()).abs().max() / Pc[n].detach().abs().max().clamp_min(1e-6)) for n, p in m.named_parameters())
+    assert worst < 1e-3, worst

@@ -33,10 +33,13 @@ def main():
 
     ga, la = grads(parallel.GradSync())
     gb, lb = grads(None)
+    gc, lc = grads(None)
     bad = [n for n in ga if not torch.equal(ga[n], gb[n])]
+    nondet = [n for n in gb if not torch.equal(gb[n], gc[n])]
+    worst = max([float((ga[n] - gb[n]).abs().max() / gb[n].abs().max().clamp_min(1e-30)) for n in bad] + [0.0])
     print("world", torch.distributed.get_world_size(), "backend", torch.distributed.get_backend(), "loss", la, lb,
-          "tensors", len(ga), "mismatching", bad[:5])
-    assert not bad and la == lb
+          "tensors", len(ga), "mismatching", len(bad), bad[:8], "worst rel", worst, "| run-to-run (no exchange) mismatching", len(nondet), nondet[:8])
+    assert not bad and not nondet and la == lb
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
     print("DDP selftest OK")

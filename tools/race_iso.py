@@ -1,0 +1,80 @@
+"""Isolation test: LayerNorm backward on the main stream with fixed inputs, repeated, while generic-engine wgrad GEMMs run on a
+side stream.  Any run whose outputs differ bitwise from the first is reported."""
+import os
+import sys
+import threading
+import time
+
+import torch
+
+sys.path.insert(0, ".")
+from painter_amd import ops  # noqa: E402
+
+DEV, T = "cuda", torch.bfloat16
+
+
+def main():
+    jitter = os.environ.get("ISO_JITTER", "pg")
+    if jitter == "pg":
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1")
+        torch.distributed.init_process_group("nccl", init_method="env://", world_size=1, rank=0)
+    g = torch.Generator().manual_seed(0)
+    R, D = 3136, 1024
+    x = torch.randn(R, D, generator=g).to(DEV)
+    gam, bet = (1 + 0.1 * torch.randn(D, generator=g)).to(DEV), torch.zeros(D, device=DEV)
+    _, mean, rstd = ops.layernorm_fwd(x, gam, bet, 1e-6, T)
+    big = torch.randn(R, 4 * D, generator=g).to(T).to(DEV)
+    dy = big[:, D:2 * D]                                     # column slice, like the tap concat gradient
+    dres0 = torch.randn(R, D, generator=g).to(DEV)
+    # side-stream load: dW = dY^T X on the generic engine (M = 3136 is not a multiple of 128)
+    sdy = torch.randn(R, 4096, generator=g).to(T).to(DEV)
+    sx = torch.randn(R, 1024, generator=g).to(T).to(DEV)
+    side = torch.cuda.Stream()
+    mode = os.environ.get("ISO_MODE", "inplace")
+
+    def one(with_side):
+        if with_side:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    ops.linear_wgrad(sdy, sx)
+        outs = []
+        for _ in range(6):
+            dres = dres0.clone()
+            dxT = torch.empty(R, D, dtype=T, device=DEV)
+            if mode == "inplace":
+                dx, gb = ops.layernorm_bwd(dy, x, mean, rstd, gam, dres=dres, dx=dres, dxT=dxT)
+            else:
+                dx, gb = ops.layernorm_bwd(dy, x, mean, rstd, gam, dres=None, dx=None, dxT=dxT)
+            outs.append((dx, dxT, gb))
+        if with_side:
+            torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        return outs
+
+    ref = one(False)[0]
+    bad = 0
+    n = int(os.environ.get("ISO_N", "300"))
+    for it in range(n):
+        for k, o in enumerate(one(True)):
+            if not (torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2])):
+                bad += 1
+                if bad <= 6:
+                    d = (o[0] - ref[0])
+                    rows = torch.nonzero(d.abs().sum(1) > 0).flatten().tolist()
+                    r = rows[0]
+                    xh = ((x[r] - mean[r]) * rstd[r]).double()
+                    dd = (d[r].double() / float(rstd[r]))
+                    A = torch.stack([-torch.ones_like(xh), -xh], 1)
+                    sol = torch.linalg.lstsq(A, dd[:, None]).solution.flatten()
+                    resid = float((A @ sol[:, None] - dd[:, None]).abs().max())
+                    dxh = (dy[r].float() * gam).double()
+                    print("iter", it, "launch", k, "rows", rows, "block", r // 4 % 1024, "wave", r % 4, "fit dc1 %.3e dc2 %.3e resid %.2e | true c1 %.4e c2 %.4e"
+                          % (float(sol[0]), float(sol[1]), resid, float(dxh.mean()), float((dxh * xh).mean())))
+    print("mode", mode, "jitter", jitter, "differing launches:", bad, "of", n * 6)
+    if jitter == "pg":
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
