@@ -38,7 +38,8 @@ enum {
 
 int pa_abi_version(void);
 /* diagnostics only (tools/): which = 0 start-up stagger of alternate workgroup rows of the 256x256 GEMM in shader cycles,
- * 1 drop that kernel's epilogue stores.  Never set by the product path. */
+ * 1 drop that kernel's epilogue stores (never set by the product path); 3 = TUNING, set by the engine: target number of workgroups
+ * of the weight-gradient GEMM (0 = 256, the whole chip; 64 when the weight gradients run on a side stream). */
 int pa_debug_set(int which, int value);
 
 /* ---- nn.Linear: y = x W^T + b.  models_painter.py:76 (qkv), :87 (proj), timm Mlp fc1/fc2 (:201,:230) ---- */

@@ -1,6 +1,7 @@
 // nn.Linear forward / dgrad / wgrad entry points on the MFMA engine (gemm_engine.h).
 // Replaces the reference's ATen addmm/mm calls at Painter/models_painter.py:76 (qkv), :87 (proj),
 // timm Mlp fc1/fc2 (:201,:230), :423 (decoder_embed) and their autograd backward (SURVEY.md 8a a4,a9,a10,a13,a17).
+#include <cstdlib>
 #include "gemm_engine.h"
 #include "gemm256.h"
 #include "../../include/painter_hip.h"
@@ -379,7 +380,14 @@ static bool wgrad_fast(int dtype, int M, int N, int K) {
 }
 static int wgrad_fast_splits(int M, int N, int K) {
     const int tiles = (N / 256) * (K / 256);
-    int s = (256 + tiles / 2) / tiles;
+    // target number of workgroups: 256 fills the chip when the kernel runs alone.  On the side stream, beside the data-gradient
+    // chain, fewer and longer workgroups are better (half the slab traffic, and the kernel does not need the whole chip):
+    // interleaved A/B on one box: 256 -> 132.9 / 133.1 images/s, 128 -> 135.0 / 134.9, 64 -> 136.1 (with 64 the fc1/fc2/qkv weight
+    // gradients need no K split at all).  pa_debug_set(3, n) / PA_WGRAD_WGS select it.
+    static const int env_target = [] { const char* v = getenv("PA_WGRAD_WGS"); return v ? atoi(v) : 0; }();
+    int target = env_target > 0 ? env_target : (g256::g_dbg[3] > 0 ? g256::g_dbg[3] : 256);
+    if (target < 16) target = 16;
+    int s = (target + tiles / 2) / tiles;
     if (s < 1) s = 1;
     const int ktiles = M / 64;
     if (s > ktiles / 4) s = ktiles / 4 > 0 ? ktiles / 4 : 1;

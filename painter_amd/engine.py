@@ -87,6 +87,8 @@ class HotPath:
         # allocator hazard on the gradient buckets, and SLP-packed fp32 VALU code mis-computing beside another kernel's MFMA
         # workgroups (build.py: -fno-slp-vectorize); DESIGN.md section 6.
         self.use_side_stream = os.environ.get("PAINTER_AMD_SIDE_STREAM", "1") != "0"
+        from ._lib import lib
+        lib.pa_debug_set(3, 64 if self.use_side_stream else 0)       # wgrad GEMM workgroup target (gemm.hip: wgrad_fast_splits)
 
     def side_stream(self, device):
         s = self._side.get(device)
