@@ -24,6 +24,7 @@ from ._lib import EPI_BIAS, EPI_BIAS_F32, EPI_BIAS_RESID
 # allocator reuse), or serialise the two streams (no concurrency)
 _DBG_KEEP = os.environ.get("PAINTER_AMD_DEBUG_KEEPALIVE", "0") == "1"
 _DBG_SERIAL = os.environ.get("PAINTER_AMD_DEBUG_SERIAL", "0") == "1"
+_SIDE_EXTRA = os.environ.get("PAINTER_AMD_SIDE_EXTRA", "1") != "0"     # rel-pos and conv weight gradients on the side stream too
 _DBG_TRACE = os.environ.get("PAINTER_AMD_DEBUG_TRACE", "0") == "1"     # checksums of the backward's intermediates -> HotPath.trace
 
 
@@ -244,6 +245,19 @@ class HotPath:
             if _DBG_SERIAL:
                 main.wait_stream(side)
 
+        def on_side(fn, *inputs):
+            """Run a parameter-gradient computation that nothing downstream consumes on the side stream (inputs: main-stream tensors)."""
+            if side is None or not _SIDE_EXTRA:
+                return fn()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                r = fn()
+            for t in inputs:
+                t.record_stream(side)
+            if _DBG_SERIAL:
+                main.wait_stream(side)
+            return r
+
         def ready(names):
             if sync is None:
                 return
@@ -264,8 +278,8 @@ class HotPath:
         G["decoder_pred.3.weight"] = tg[128:320].reshape(3, c.dec, 1, 1)
         G["decoder_pred.3.bias"] = tg[320:323]
         npix = B * c.H * c.W
-        G["decoder_pred.0.weight"] = ops.conv3x3_wgrad(dy3, S.E)
-        G["decoder_pred.0.bias"] = ops.colsum(dy3.view(npix, c.dec))
+        G["decoder_pred.0.weight"], G["decoder_pred.0.bias"] = on_side(
+            lambda: (ops.conv3x3_wgrad(dy3, S.E), ops.colsum(dy3.view(npix, c.dec))), dy3, S.E)
         dE = ops.conv3x3_dgrad_unshuffle(dy3, S.wf, B, c.Hp, c.Wp, c.P)
         del dy3
         param_grads("decoder_embed.weight", "decoder_embed.bias", dE, S.concat)
@@ -318,8 +332,10 @@ class HotPath:
             tr("%d.dao" % i, dao)
             del dyA
             rcatT = ops.relpos_pack_t(P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], c.Hp, c.Wp, T)
-            dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, ao, dao, lse, Bc, L, c.heads, c.Hp, c.Wp, c.scale)
-            tr("%d.dqkv" % i, dqkv); tr("%d.drcat" % i, drcat)
+            dqkv, dG = ops.attn_bwd_core(qkv, rcat, rcatT, ao, dao, lse, Bc, L, c.heads, c.Hp, c.Wp, c.scale)
+            drcat = on_side(lambda: ops.attn_bwd_relpos(dG, qkv, rcat.shape[0], Bc, L, c.heads, c.Hp, c.Wp), dG, qkv)
+            del dG
+            tr("%d.dqkv" % i, dqkv)
             nh, nw = 2 * c.Hp - 1, 2 * c.Wp - 1
             G[pre + "attn.rel_pos_h"] = drcat[:nh]
             G[pre + "attn.rel_pos_w"] = drcat[nh:nh + nw]

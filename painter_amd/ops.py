@@ -164,8 +164,8 @@ def relpos_pack_t(rel_pos_h, rel_pos_w, Hp, Wp, dtype):
     return rcatT
 
 
-def attn_bwd(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale):
-    """-> (dqkv T [batch*L, 3*heads*64], drcat f32 [NRP, 64])."""
+def attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale):
+    """-> (dqkv T [batch*L, 3*heads*64], dG T [batch*L, heads*NRP]): the data gradients and the per-query bias gradients."""
     T = qkv.dtype
     dev = qkv.device
     nrp = rcat.shape[0]
@@ -177,11 +177,23 @@ def attn_bwd(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale):
     aux = workspace(lib.pa_attn_bwd_aux_bytes(batch, L, heads, Hp, Wp), dev, slot=1)
     check(lib.pa_attn_bwd(code(T), p(qkv), qkv.stride(0), p(rcat), p(rcatT), p(dout), dout.stride(0), p(lse), p(delta),
                           p(dqkv), p(dG), p(aux), batch, L, heads, Hp, Wp, float(scale), stream()), "pa_attn_bwd")
-    drcat = torch.empty((nrp, 64), dtype=torch.float32, device=dev)
-    ws = workspace(lib.pa_attn_bwd_relpos_workspace_bytes(code(T), batch, L, heads, Hp, Wp), dev)
+    return dqkv, dG
+
+
+def attn_bwd_relpos(dG, qkv, nrp, batch, L, heads, Hp, Wp):
+    """-> drcat f32 [NRP, 64] = d[rel_pos_h ; rel_pos_w ; pad]: a parameter gradient (nothing downstream consumes it)."""
+    T = qkv.dtype
+    drcat = torch.empty((nrp, 64), dtype=torch.float32, device=qkv.device)
+    ws = workspace(lib.pa_attn_bwd_relpos_workspace_bytes(code(T), batch, L, heads, Hp, Wp), qkv.device)
     check(lib.pa_attn_bwd_relpos(code(T), p(dG), p(qkv), qkv.stride(0), p(drcat), p(ws), batch, L, heads, Hp, Wp,
                                  stream()), "pa_attn_bwd_relpos")
-    return dqkv, drcat
+    return drcat
+
+
+def attn_bwd(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale):
+    """-> (dqkv T [batch*L, 3*heads*64], drcat f32 [NRP, 64])."""
+    dqkv, dG = attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale)
+    return dqkv, attn_bwd_relpos(dG, qkv, rcat.shape[0], batch, L, heads, Hp, Wp)
 
 
 # ------------------------------------------------------------------------------------------- tokens / pos / merge
