@@ -294,3 +294,42 @@ def test_conv64_bf16_tile_kernels(B, Hi, Wi):
     dw_ref = torch.nn.grad.conv2d_weight(xn, (64, 64, 3, 3), dyn, padding=1)
     assert relerr(dw, dw_ref) < 1e-4
     assert torch.equal(dw, ops.conv3x3_wgrad(dy, x))
+
+
+def test_layernorm_bwd_bitstable_beside_concurrent_mfma_kernels():
+    """Regression for the SLP / packed-fp32 hazard (painter_amd/build.py): LayerNorm backward on the current
+    stream, fixed inputs, while MFMA weight-gradient GEMMs run on a second stream -- every launch must be bit-identical to the
+    undisturbed one (with SLP-vectorised code ~1 % of the launches returned one wrong row)."""
+    T = torch.bfloat16
+    R, D = 3136, 1024
+    x = gen((R, D), 1)
+    gam, bet = 1 + gen((D,), 2, 0.1), gen((D,), 3, 0.1)
+    _, mean, rstd = ops.layernorm_fwd(x, gam, bet, 1e-6, T)
+    dy = gen((R, 4 * D), 4, 1.0, T)[:, D:2 * D]
+    dres0 = gen((R, D), 5)
+    sdy, sx = gen((R, 4096), 6, 1.0, T), gen((R, 1024), 7, 1.0, T)          # M = 3136: generic-engine wgrad, as in the model at B=2
+    side = torch.cuda.Stream()
+
+    def run(load):
+        if load:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    ops.linear_wgrad(sdy, sx)
+        outs = []
+        for _ in range(6):
+            dres = dres0.clone()
+            dxT = torch.empty(R, D, dtype=T, device=DEV)
+            dx, gb = ops.layernorm_bwd(dy, x, mean, rstd, gam, dres=dres, dx=dres, dxT=dxT)
+            outs.append((dx, dxT, gb))
+        if load:
+            torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        return outs
+
+    ref = run(False)[0]
+    bad = 0
+    for _ in range(120):
+        for o in run(True):
+            bad += int(not (torch.equal(o[0], ref[0]) and torch.equal(o[1], ref[1]) and torch.equal(o[2], ref[2])))
+    assert bad == 0, "%d of 720 launches differ" % bad
