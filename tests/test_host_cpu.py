@@ -89,3 +89,39 @@ def test_no_cpu_fallback():
     x = torch.zeros(1, 3, 128, 64)
     with pytest.raises(Exception):
         m(x, x, bool_masked_pos=torch.zeros(1, 32), valid=torch.ones_like(x))
+
+
+REF_PAINTER = "/root/reference/Painter"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_PAINTER), reason="reference tree not mounted (GPU box)")
+def test_fused_adamw_takes_the_references_layer_decay_groups_and_lr_schedule():
+    """The unchanged reference helpers drive our optimizer object: util/lr_decay.param_groups_lrd (main_train.py:344-347) builds the
+    groups, util/lr_sched.adjust_learning_rate (engine_train.py:56) rewrites their lr through `lr_scale`.  Host logic only."""
+    import importlib.util
+    import types
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location("ref_" + name, os.path.join(REF_PAINTER, "util", name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+
+    lrd, lr_sched = load("lr_decay"), load("lr_sched")
+    from painter_amd import models_painter, optim as PO
+    m = models_painter.painter_vit_large_patch16_input896x448_win_dec64_8glb_sl1()
+    groups = lrd.param_groups_lrd(m, 0.05, no_weight_decay_list=m.no_weight_decay(), layer_decay=0.8)
+    assert len(groups) == 52 and len(groups) <= PO.MAX_GROUPS
+    assert sum(len(g["params"]) for g in groups) == len(list(m.parameters()))
+    opt = PO.AdamW(groups, lr=1e-3, betas=(0.9, 0.999))
+    args = types.SimpleNamespace(lr=1e-3, min_lr=1e-5, warmup_epochs=1, epochs=15)
+    lr = lr_sched.adjust_learning_rate(opt, 0.5, args)
+    assert abs(lr - 5e-4) < 1e-12
+    for g in opt.param_groups:
+        assert abs(g["lr"] - lr * g["lr_scale"]) < 1e-15 and g["weight_decay"] in (0.0, 0.05)
+    # decay rule of the reference: 1-D parameters and pos_embed are not decayed
+    nd = {id(p) for g in opt.param_groups if g["weight_decay"] == 0.0 for p in g["params"]}
+    for n, p in m.named_parameters():
+        assert (id(p) in nd) == (p.ndim == 1 or n in ("pos_embed", "cls_token")), n
+    sd = opt.state_dict()
+    assert len(sd["param_groups"]) == 52
