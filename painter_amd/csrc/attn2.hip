@@ -5,7 +5,8 @@
 // What changed against generation 1, and why (rocprof: 1 workgroup of 4-7 waves per CU, 96-270 TFLOP/s):
 //   * LDS per query row drops from 672 B (two fp32 k-space tables) to 224 B: the kw table stays fp32 (it is loaded
 //     straight into the S accumulator as the MFMA's C operand -- no VALU add), the kh table is bf16 (one scalar per run of
-//     4 keys), and the bias GRADIENT needs no table at all (next point).  3 workgroups of 4 waves fit a CU.
+//     4 keys), and the bias GRADIENT needs no table at all (next point).  3 workgroups of 4 waves fit a CU (4 for the
+//     single-stage forward kernel, the default).
 //   * d bias / d (kw), d bias / d (kh) are contractions of dS with one-hot key patterns, so they run on the matrix pipe:
 //     E^T[32][32 keys] . dS^T accumulates rows 0..Wp-1 = dGw[q][kw] over all key tiles and rows 28..31 = this tile's
 //     dGh[q][kh0..kh0+3]; the latter slide through a 4-deep register window (key rows are visited in order) and replace
@@ -16,8 +17,8 @@
 //   * forward: the running max is only re-based when a tile exceeds it by more than 2^6 (wave-uniform, rare branch), so
 //     the usual O rescale and the subtraction of the new max disappear from the per-tile VALU stream.
 // Work split (all three): workgroup = 4 waves, wave = 32 rows (queries, or keys in dKV), lane = one row end to end;
-// 32-row tiles of the other axis stream through LDS, register-staged (global -> VGPR early, VGPR -> LDS late), one
-// barrier per tile, double buffered.
+// 32-row tiles of the other axis stream through LDS, register-staged (global -> VGPR early, VGPR -> LDS late); STAGES = 2
+// double-buffers them (one barrier per tile), STAGES = 1 trades the second stage for one more resident workgroup.
 #include "attn_common.h"
 #include "../../include/painter_hip.h"
 #include "attn2.h"

@@ -81,9 +81,10 @@ DEVI int lds64(int row, int gran) { return row * 64 + ((gran ^ ((row >> 2) & 7))
 
 // ---------------------------------------------------------------------------------------------
 // Cross-lane exchanges on the VALU only (DPP within a row of 16 lanes, gfx950's v_permlane16_swap / v_permlane32_swap across rows).
-// hipcc lowers __shfl_xor to ds_bpermute_b32, i.e. through the LDS unit; with a second kernel's workgroups resident on the same
-// CU (two streams, RCCL) a LayerNorm-backward row sum built from ds_bpermute came back wrong about once in 100 launches
-// (tools/race_iso.py: exactly one row of dx off by its c2 term).  These forms never leave the SIMD.
+// hipcc lowers __shfl_xor to ds_bpermute_b32, i.e. a round trip through the LDS unit per butterfly step; these forms never leave the
+// SIMD and cost one VALU op each.  (They were introduced while chasing a rare LayerNorm-backward mismatch under two-stream execution;
+// that turned out to be SLP-packed fp32 math, see build.py's -fno-slp-vectorize and DESIGN.md section 6 -- the DPP forms stayed
+// because they are cheaper.)
 template <int CTRL> DEVI float lane_dpp(float v) {
     const int i = __builtin_bit_cast(int, v);
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false));
