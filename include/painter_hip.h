@@ -194,6 +194,35 @@ int pa_adamw_step(const PaOptTensor* table, int ntensors, int nchunks, const PaO
                   float eps, float* steps, const float* norm_info, const float* grad_scale, const float* found_inf,
                   float max_norm, hipStream_t stream);
 
+/* ---- SegGPT pre-/post-processing on the device.  Replaces the PIL / numpy / CPU-torch work of
+ * SegGPT/SegGPT_inference/seggpt_engine.py: inference_image :56-103, inference_video :106-181, run_one_image :26-53.
+ * Images are uint8 [H][W][C] (C <= 4), densely packed, in device memory; everything is bit-exact with the reference's host path:
+ * integer arithmetic for the resize passes, float64 with one rounding per operation for normalise / de-normalise / blend. ---- */
+/* One separable pass of Pillow's ImagingResample for 8-bit pixels (`Image.resize`, default BICUBIC; :62, :66, :117, :136):
+ * out = clip8((2^21 + sum_t src[first + t] * coeffs[o][t]) >> 22) along the width (vertical = 0: dst is [src_h][dst_w]) or the
+ * height (vertical = 1: dst is [dst_h][src_w]).  bounds: int32 [n_out][2] = (first, taps); coeffs: int32 [n_out][ksize]. */
+int pa_resample_u8(const void* src, int src_h, int src_w, void* dst, int dst_h, int dst_w, int channels, const void* bounds,
+                   const void* coeffs, int ksize, int vertical, hipStream_t stream);
+/* `Image.resize(size, Image.NEAREST)` (:70, :121) and any other index-table gather: dst[y][x] = src[ytab[y]][xtab[x]], 0 where a
+ * table entry is negative.  ytab: int32 [dst_h], xtab: int32 [dst_w]. */
+int pa_gather_u8(const void* src, int src_h, int src_w, void* dst, int dst_h, int dst_w, int channels, const void* ytab,
+                 const void* xtab, hipStream_t stream);
+/* :73-92 + :28-34: imgs[n] = [prompt_n ; query], tgts[n] = [target_n ; target_n] along H, (v / div - mean) / std in float64, written
+ * as float32 NCHW [n_prompts][3][2*res_h][res_w].  prompts / targets: uint8 [n_prompts][res_h][res_w][3]; query: uint8
+ * [res_h][res_w][3]; target_div: DEVICE double [n_prompts] (255 for image-scale targets, 1 for the cached {0,1} masks, :166-171). */
+int pa_seggpt_stitch(const void* prompts, const void* targets, const void* target_div, const void* query, float* imgs,
+                     float* tgts, int n_prompts, int res_h, int res_w, hipStream_t stream);
+/* :49-53: pred = the model's float32 tokens of sample 0, [2*res_h/patch * res_w/patch][patch*patch*3]; out = float64
+ * [res_h][res_w][3] = clip((lower half of unpatchify(pred) * std + mean) * 255, 0, 255). */
+int pa_seggpt_decode(const float* pred, void* out_f64, int res_h, int res_w, int patch, hipStream_t stream);
+/* :166-171: out uint8 [res_h][res_w][3] = (mean over channels of the decoded picture > 128), the next video prompt target. */
+int pa_seggpt_mask(const float* pred, void* out_u8, int res_h, int res_w, int patch, hipStream_t stream);
+/* :95-102, :173-179 fused: decode, nearest-resize to out_h x out_w through ytab / xtab (int32 source rows / columns of the
+ * res_h x res_w picture, F.interpolate(mode='nearest') rule), out = uint8(image * (0.6 * picture / 255 + 0.4)) (truncation).
+ * image, out: uint8 [out_h][out_w][3]. */
+int pa_seggpt_blend(const float* pred, const void* image, void* out, int out_h, int out_w, const void* ytab, const void* xtab,
+                    int res_h, int res_w, int patch, hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -147,3 +147,8 @@ def load_reference_painter():
 def load_reference_seggpt():
     """-> the reference module object of SegGPT/SegGPT_inference/models_seggpt.py."""
     return _load("ref_models_seggpt", os.path.join(SEGGPT_DIR, "models_seggpt.py"), SEGGPT_DIR)
+
+
+def load_reference_seggpt_engine():
+    """-> the reference module object of SegGPT/SegGPT_inference/seggpt_engine.py (cv2 is a stand-in: only inference_video needs it)."""
+    return _load("ref_seggpt_engine", os.path.join(SEGGPT_DIR, "seggpt_engine.py"), SEGGPT_DIR)
