@@ -265,7 +265,7 @@ def main():
             out["optimizer_step"] = optimizer_step_ms(model, step)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if world > 1 or parallel._SELFTEST:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
