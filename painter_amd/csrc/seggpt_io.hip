@@ -3,8 +3,9 @@
 //
 // All of it is HBM- and launch-bound integer / byte work (a 1080p frame is 6 MB, the 448 x 448 pictures 0.6 MB), so the kernels are
 // plain coalesced one-thread-per-output-pixel gathers: rows of the output map to consecutive lanes, every byte of the big frame is
-// read once and written once, the small operands (coefficient / index tables, the 1568 x 768 token matrix) stay in L2.  No MFMA, no
-// LDS: there is no reuse LDS could capture that L2 does not already (each output pixel's taps overlap its neighbour's by < 20 B).
+// read once and written once, the small operands (coefficient / index tables, the 1568 x 768 token matrix) stay in L2.  No MFMA.
+// LDS only where there is reuse to capture: the horizontal resize pass, whose ~19 taps per output pixel overlap 4x along the row,
+// stages each source row once.
 //
 // Bit-exactness with the reference's host path is the contract:
 //   * resize passes: Pillow's 8-bit fixed point (int32 accumulator seeded with 2^21, >> 22, clamp) -- pure integer;
@@ -57,6 +58,47 @@ __global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restr
 #pragma unroll
     for (int c = 0; c < MAXC; ++c)
         if (c < C) d[c] = clip8(acc[c]);
+}
+
+// Horizontal pass, one workgroup per input row: the row (a few KB) is staged in LDS with aligned dword loads -- every source byte
+// crosses HBM/L2 once, coalesced -- and the taps are LDS byte reads.  The direct kernel above makes ~57 byte-granular global loads
+// per output pixel (30.6 us for 1080p -> 448 columns); this one is bounded by the 6 MB read.  LDS image keeps the row's misalignment
+// (off = address & 3) so that global dword i lands on an aligned LDS dword.
+__global__ __launch_bounds__(256) void resample_h_lds_kernel(const uint8_t* __restrict__ src, int sw, uint8_t* __restrict__ dst, int dw, int C,
+                                                             const int* __restrict__ bounds, const int* __restrict__ coeffs, int ksize) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char row_lds[];
+    const int y = blockIdx.x, tid = threadIdx.x;
+    const int nbytes = sw * C;
+    const uint8_t* row = src + (size_t)y * nbytes;
+    const int off = (int)((uintptr_t)row & 3);
+    int head = (4 - off) & 3;
+    if (head > nbytes) head = nbytes;
+    const int ndw = (nbytes - head) >> 2, tail0 = head + 4 * ndw;
+    if (tid < head) row_lds[off + tid] = row[tid];
+    const uint32_t* rp = (const uint32_t*)(row + head);
+    uint32_t* lp = (uint32_t*)(row_lds + off + head);
+    for (int i = tid; i < ndw; i += 256) lp[i] = rp[i];
+    if (tid < nbytes - tail0) row_lds[off + tail0 + tid] = row[tail0 + tid];
+    __syncthreads();
+    const unsigned char* r = row_lds + off;
+    for (int x = tid; x < dw; x += 256) {
+        const int first = bounds[2 * x], taps = bounds[2 * x + 1];
+        const int* k = coeffs + (size_t)x * ksize;
+        int acc[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) acc[c] = 1 << (PRECISION_BITS - 1);
+        const unsigned char* s = r + first * C;
+        for (int t = 0; t < taps; ++t, s += C) {
+            const int kt = k[t];
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c)
+                if (c < C) acc[c] += (int)s[c] * kt;
+        }
+        uint8_t* d = dst + ((size_t)y * dw + x) * C;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) d[c] = clip8(acc[c]);
+    }
 }
 
 __global__ __launch_bounds__(256) void gather_u8_kernel(const uint8_t* __restrict__ src, int sw, uint8_t* __restrict__ dst, int dw, int C,
@@ -167,6 +209,9 @@ int pa_resample_u8(const void* src, int src_h, int src_w, void* dst, int dst_h, 
     if (vertical)
         PA_LAUNCH(resample_u8_kernel<true>, grid2(dst_w, dst_h), dim3(256), 0, stream, (const uint8_t*)src, src_w, (uint8_t*)dst, dst_w, channels,
                   (const int*)bounds, (const int*)coeffs, ksize);
+    else if ((size_t)src_w * channels + 8 <= 48 * 1024)          // the row fits LDS: staged kernel, one workgroup per row
+        PA_LAUNCH(resample_h_lds_kernel, dim3((unsigned)dst_h), dim3(256), ((size_t)src_w * channels + 8 + 15) & ~(size_t)15, stream,
+                  (const uint8_t*)src, src_w, (uint8_t*)dst, dst_w, channels, (const int*)bounds, (const int*)coeffs, ksize);
     else
         PA_LAUNCH(resample_u8_kernel<false>, grid2(dst_w, dst_h), dim3(256), 0, stream, (const uint8_t*)src, src_w, (uint8_t*)dst, dst_w, channels,
                   (const int*)bounds, (const int*)coeffs, ksize);
