@@ -208,27 +208,40 @@ def inference_image(model, device, img_path, img2_paths, tgt2_paths, out_path):
     Image.fromarray(output.cpu().numpy()).save(out_path)
 
 
-@torch.no_grad()
+class _FrameLoop:
+    """State of the video loop (:125-132): the resized prompt pair and the FIFO caches of earlier (frame, predicted mask) pairs."""
+
+    def __init__(self, model, device, num_frames, img2, tgt2):
+        self.res, self.hres = 448, 448
+        self.model = model
+        self.io = _io_for(model, device, self.res, self.hres)
+        self.img2 = self.io.resize(self.io.upload(img2), (self.res, self.hres))
+        self.tgt2 = self.io.resize(self.io.upload(tgt2), (self.res, self.hres), nearest=True)
+        self.frames_cache, self.target_cache = Cache(num_frames), Cache(num_frames)
+
+    @torch.no_grad()
+    def step(self, frame):
+        io = self.io
+        input_image = io.upload(frame)
+        image = io.resize(input_image, (self.res, self.hres))
+        prompts = torch.stack([self.img2] + list(self.frames_cache))
+        targets = torch.stack([self.tgt2] + list(self.target_cache))
+        div = [255.0] + [1.0] * len(self.target_cache)       # cached targets are {0,1} masks, used as they are (:166-171)
+        imgs, tgts = io.stitch(prompts, targets, image, div)
+        y = _forward(self.model, imgs, tgts)
+        self.frames_cache.append(image)
+        self.target_cache.append(io.mask(y))
+        return io.blend(y, input_image).cpu().numpy()
+
+
 def inference_frames(model, device, frames, num_frames, img2, tgt2):
     """The loop body of inference_video (:130-179) without the cv2 container I/O: `frames` yields RGB uint8 [H][W][3] arrays, `img2`
     and `tgt2` are the prompt image / prompt target as RGB uint8 arrays of any size, `num_frames` is the size of the prompt cache
-    of earlier (frame, predicted mask) pairs.  Yields one blended RGB uint8 [H][W][3] array per frame."""
-    res, hres = 448, 448
-    io = _io_for(model, device, res, hres)
-    img2 = io.resize(io.upload(img2), (res, hres))
-    tgt2 = io.resize(io.upload(tgt2), (res, hres), nearest=True)
-    frames_cache, target_cache = Cache(num_frames), Cache(num_frames)
+    of earlier (frame, predicted mask) pairs.  Yields one blended RGB uint8 [H][W][3] array per frame.  (Grad mode is switched off
+    per frame inside `_FrameLoop.step`, not around the generator, so the consumer's code between frames keeps its own grad mode.)"""
+    loop = _FrameLoop(model, device, num_frames, img2, tgt2)
     for frame in frames:
-        input_image = io.upload(frame)
-        image = io.resize(input_image, (res, hres))
-        prompts = torch.stack([img2] + list(frames_cache))
-        targets = torch.stack([tgt2] + list(target_cache))
-        div = [255.0] + [1.0] * len(target_cache)            # cached targets are {0,1} masks, used as they are (:166-171)
-        imgs, tgts = io.stitch(prompts, targets, image, div)
-        y = _forward(model, imgs, tgts)
-        frames_cache.append(image)
-        target_cache.append(io.mask(y))
-        yield io.blend(y, input_image).cpu().numpy()
+        yield loop.step(frame)
 
 
 def inference_video(model, device, vid_path, num_frames, img2_paths, tgt2_paths, out_path):

@@ -170,8 +170,15 @@ def test_inference_image_with_the_vit_large_network(tmp_path):
     out = np.array(Image.open(tmp_path / "out.png"))
     y0 = seen["y"][0].float().cpu().numpy()
     assert seen["imgs"].shape == (2, 3, 896, 448) and np.isfinite(y0).all()
-    q, _, _ = C.image_case_inputs()
+    q, prompts, targets = C.image_case_inputs()
     assert np.array_equal(out, O.blend(y0, q, C.HRES, C.RES, C.PATCH))
+    # the video loop with the real network (feature ensemble from the second frame on); the caller's grad mode is left alone
+    assert torch.is_grad_enabled()
+    frames = [C.picture(41, 270, 480), C.picture(42, 270, 480)]
+    for i, blended in enumerate(E.inference_frames(net, "cuda", iter(frames), 1, prompts[0], targets[0])):
+        assert torch.is_grad_enabled()
+        assert seen["imgs"].shape[0] == i + 1
+        assert np.array_equal(blended, O.blend(seen["y"][0].float().cpu().numpy(), frames[i], C.HRES, C.RES, C.PATCH))
 
 
 def test_c_abi_rejects_bad_arguments():
