@@ -223,6 +223,38 @@ int pa_seggpt_mask(const float* pred, void* out_u8, int res_h, int res_w, int pa
 int pa_seggpt_blend(const float* pred, const void* image, void* out, int out_h, int out_w, const void* ytab, const void* xtab,
                     int res_h, int res_w, int patch, hipStream_t stream);
 
+/* ---- Painter training input pipeline, pixel work on the device.  Replaces, per sample, the PIL / CPU-torch work of
+ * Painter/data/pairdataset.py:106-190 under the transform stack of Painter/main_train.py:232-251 (Painter/data/pair_transforms.py).
+ * Random parameters (crop boxes, jitter order and factors, flip flags) are inputs: drawing them stays on the host. ---- */
+/* RandomResizedCrop on decoded uint8 pictures (pair_transforms.py:152-163 -> PIL crop + resize): pa_resample_u8 / pa_gather_u8 on a
+ * box of a larger picture -- src points at the box's first pixel, rows are src_row_bytes apart. */
+int pa_resample_u8_box(const void* src, int64_t src_row_bytes, int src_h, int src_w, void* dst, int dst_h, int dst_w, int channels,
+                       const void* bounds, const void* coeffs, int ksize, int vertical, hipStream_t stream);
+int pa_gather_u8_box(const void* src, int64_t src_row_bytes, int src_h, int src_w, void* dst, int dst_h, int dst_w, int channels,
+                     const void* ytab, const void* xtab, hipStream_t stream);
+/* ColorJitter (pair_transforms.py:236-247 -> PIL ImageEnhance.Brightness / Contrast / Color and the HSV hue shift), in place on uint8
+ * [batch][h][w][3].  ops: DEVICE int32 [batch][4], the op of each of the four slots in applied order (0 brightness, 1 contrast,
+ * 2 saturation, 3 hue, negative = none); factors: DEVICE float [batch][4] (hue slot: the uint8 added to the H plane, as a float);
+ * ops_host: HOST copy of ops, or NULL (then every slot and its mean pass is launched).  Bit-exact with Pillow. */
+int64_t pa_color_jitter_workspace_bytes(int batch);
+int pa_color_jitter(void* images, const void* ops, const void* factors, const void* ops_host, void* workspace, int batch, int h, int w,
+                    hipStream_t stream);
+/* RandomHorizontalFlip + ToTensor + Normalize (pair_transforms.py:199-203, :72, :101) and the two-pair stitch (pairdataset.py:100-104):
+ * uint8 [batch][h][w][3] -> rows [row0, row0 + h) of float32 [batch][3][canvas_h][w]; flip: DEVICE int32 [batch]. */
+int pa_to_tensor_normalize(const void* images, const void* flip, float* canvas, int batch, int h, int w, int canvas_h, int row0,
+                           hipStream_t stream);
+/* Second RandomResizedCrop on the float canvases (main_train.py:248-250): dst[b] = interpolate(src[b][:, top:top+bh, left:left+bw],
+ * size = (h, w)), bicubic (A = -0.75, align_corners = False, no antialias) or nearest.  boxes: DEVICE int32 [batch][4] =
+ * (top, left, bh, bw).  src != dst. */
+int pa_resized_crop_f32(const float* src, float* dst, const void* boxes, int batch, int channels, int h, int w, int nearest,
+                        hipStream_t stream);
+/* `valid` rules (pairdataset.py:152-180) on float32 [batch][3][plane] targets.  modes: DEVICE int32 [batch] (0 ones; 1 target < thres
+ * -> 0; 2 target > thres -> 10 and all 0 if fewer than 300 foreground elements; 3 all 0 if fewer than 300 foreground elements);
+ * thres: DEVICE float [batch][3]. */
+int64_t pa_pair_valid_workspace_bytes(int batch);
+int pa_pair_valid(const float* tgts, float* valid, const void* modes, const void* thres, void* workspace, int batch, int plane,
+                  hipStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

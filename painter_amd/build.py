@@ -20,8 +20,8 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 if os.environ.get("PA_SLP") != "1":
     FLAGS = FLAGS + ["-fno-slp-vectorize"]
-# seggpt_io.hip reproduces float64 host arithmetic bit for bit: no fused multiply-add there.
-EXTRA = {"seggpt_io.hip": ["-ffp-contract=off"]}
+# seggpt_io.hip / pair_io.hip reproduce host float arithmetic (numpy, Pillow) bit for bit: no fused multiply-add there.
+EXTRA = {"seggpt_io.hip": ["-ffp-contract=off"], "pair_io.hip": ["-ffp-contract=off"]}
 
 
 def _hipcc():

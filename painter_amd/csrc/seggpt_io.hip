@@ -36,7 +36,7 @@ DEVI uint8_t clip8(int acc) {
 // grid: x = blocks of 256 output columns, y = output rows.  Horizontal: taps walk along the row (3 B apart, served by L1/L2);
 // vertical: taps walk down the rows, lanes stay on consecutive columns.
 template <bool VERT>
-__global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restrict__ src, int sw, uint8_t* __restrict__ dst, int dw, int C,
+__global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restrict__ src, size_t row_bytes, uint8_t* __restrict__ dst, int dw, int C,
                                                           const int* __restrict__ bounds, const int* __restrict__ coeffs, int ksize) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= dw) return;
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restr
     int acc[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) acc[c] = 1 << (PRECISION_BITS - 1);
-    const uint8_t* s = VERT ? src + ((size_t)first * sw + x) * C : src + ((size_t)y * sw + first) * C;
-    const size_t step = VERT ? (size_t)sw * C : (size_t)C;
+    const uint8_t* s = VERT ? src + (size_t)first * row_bytes + (size_t)x * C : src + (size_t)y * row_bytes + (size_t)first * C;
+    const size_t step = VERT ? row_bytes : (size_t)C;
     for (int t = 0; t < taps; ++t, s += step) {
         const int kt = k[t];
 #pragma unroll
@@ -64,12 +64,12 @@ __global__ __launch_bounds__(256) void resample_u8_kernel(const uint8_t* __restr
 // crosses HBM/L2 once, coalesced -- and the taps are LDS byte reads.  The direct kernel above makes ~57 byte-granular global loads
 // per output pixel (30.6 us for 1080p -> 448 columns); this one is bounded by the 6 MB read.  LDS image keeps the row's misalignment
 // (off = address & 3) so that global dword i lands on an aligned LDS dword.
-__global__ __launch_bounds__(256) void resample_h_lds_kernel(const uint8_t* __restrict__ src, int sw, uint8_t* __restrict__ dst, int dw, int C,
+__global__ __launch_bounds__(256) void resample_h_lds_kernel(const uint8_t* __restrict__ src, size_t row_bytes, int sw, uint8_t* __restrict__ dst, int dw, int C,
                                                              const int* __restrict__ bounds, const int* __restrict__ coeffs, int ksize) {
     extern __shared__ __attribute__((aligned(16))) unsigned char row_lds[];
     const int y = blockIdx.x, tid = threadIdx.x;
     const int nbytes = sw * C;
-    const uint8_t* row = src + (size_t)y * nbytes;
+    const uint8_t* row = src + (size_t)y * row_bytes;
     const int off = (int)((uintptr_t)row & 3);
     int head = (4 - off) & 3;
     if (head > nbytes) head = nbytes;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void resample_h_lds_kernel(const uint8_t* __re
     }
 }
 
-__global__ __launch_bounds__(256) void gather_u8_kernel(const uint8_t* __restrict__ src, int sw, uint8_t* __restrict__ dst, int dw, int C,
+__global__ __launch_bounds__(256) void gather_u8_kernel(const uint8_t* __restrict__ src, size_t row_bytes, uint8_t* __restrict__ dst, int dw, int C,
                                                         const int* __restrict__ ytab, const int* __restrict__ xtab) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= dw) return;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void gather_u8_kernel(const uint8_t* __restric
         for (int c = 0; c < C; ++c) d[c] = 0;
         return;
     }
-    const uint8_t* s = src + ((size_t)sy * sw + sx) * C;
+    const uint8_t* s = src + (size_t)sy * row_bytes + (size_t)sx * C;
     for (int c = 0; c < C; ++c) d[c] = s[c];
 }
 
@@ -202,29 +202,42 @@ inline dim3 grid2(int w, int h, int z = 1) { return dim3((unsigned)((w + 255) / 
 
 extern "C" {
 
-int pa_resample_u8(const void* src, int src_h, int src_w, void* dst, int dst_h, int dst_w, int channels, const void* bounds,
-                   const void* coeffs, int ksize, int vertical, hipStream_t stream) {
-    if (channels < 1 || channels > MAXC || dst_h < 1 || dst_w < 1 || dst_h > 65535) return (int)hipErrorInvalidValue;
+// src rows are src_row_bytes apart (>= src_w * channels): a crop box is a pointer offset plus the parent's row pitch.
+int pa_resample_u8_box(const void* src, int64_t src_row_bytes, int src_h, int src_w, void* dst, int dst_h, int dst_w, int channels,
+                       const void* bounds, const void* coeffs, int ksize, int vertical, hipStream_t stream) {
+    if (channels < 1 || channels > MAXC || dst_h < 1 || dst_w < 1 || dst_h > 65535 || src_row_bytes < (int64_t)src_w * channels)
+        return (int)hipErrorInvalidValue;
     if (vertical ? dst_w != src_w : dst_h != src_h) return (int)hipErrorInvalidValue;
+    const size_t rb = (size_t)src_row_bytes;
     if (vertical)
-        PA_LAUNCH(resample_u8_kernel<true>, grid2(dst_w, dst_h), dim3(256), 0, stream, (const uint8_t*)src, src_w, (uint8_t*)dst, dst_w, channels,
+        PA_LAUNCH(resample_u8_kernel<true>, grid2(dst_w, dst_h), dim3(256), 0, stream, (const uint8_t*)src, rb, (uint8_t*)dst, dst_w, channels,
                   (const int*)bounds, (const int*)coeffs, ksize);
     else if ((size_t)src_w * channels + 8 <= 48 * 1024)          // the row fits LDS: staged kernel, one workgroup per row
         PA_LAUNCH(resample_h_lds_kernel, dim3((unsigned)dst_h), dim3(256), ((size_t)src_w * channels + 8 + 15) & ~(size_t)15, stream,
-                  (const uint8_t*)src, src_w, (uint8_t*)dst, dst_w, channels, (const int*)bounds, (const int*)coeffs, ksize);
+                  (const uint8_t*)src, rb, src_w, (uint8_t*)dst, dst_w, channels, (const int*)bounds, (const int*)coeffs, ksize);
     else
-        PA_LAUNCH(resample_u8_kernel<false>, grid2(dst_w, dst_h), dim3(256), 0, stream, (const uint8_t*)src, src_w, (uint8_t*)dst, dst_w, channels,
+        PA_LAUNCH(resample_u8_kernel<false>, grid2(dst_w, dst_h), dim3(256), 0, stream, (const uint8_t*)src, rb, (uint8_t*)dst, dst_w, channels,
                   (const int*)bounds, (const int*)coeffs, ksize);
+    LAUNCH_CHECK();
+}
+
+int pa_resample_u8(const void* src, int src_h, int src_w, void* dst, int dst_h, int dst_w, int channels, const void* bounds,
+                   const void* coeffs, int ksize, int vertical, hipStream_t stream) {
+    return pa_resample_u8_box(src, (int64_t)src_w * channels, src_h, src_w, dst, dst_h, dst_w, channels, bounds, coeffs, ksize, vertical, stream);
+}
+
+int pa_gather_u8_box(const void* src, int64_t src_row_bytes, int src_h, int src_w, void* dst, int dst_h, int dst_w, int channels,
+                     const void* ytab, const void* xtab, hipStream_t stream) {
+    (void)src_h;
+    if (channels < 1 || dst_h < 1 || dst_w < 1 || dst_h > 65535 || src_row_bytes < (int64_t)src_w * channels) return (int)hipErrorInvalidValue;
+    PA_LAUNCH(gather_u8_kernel, grid2(dst_w, dst_h), dim3(256), 0, stream, (const uint8_t*)src, (size_t)src_row_bytes, (uint8_t*)dst, dst_w, channels,
+              (const int*)ytab, (const int*)xtab);
     LAUNCH_CHECK();
 }
 
 int pa_gather_u8(const void* src, int src_h, int src_w, void* dst, int dst_h, int dst_w, int channels, const void* ytab,
                  const void* xtab, hipStream_t stream) {
-    (void)src_h;
-    if (channels < 1 || dst_h < 1 || dst_w < 1 || dst_h > 65535) return (int)hipErrorInvalidValue;
-    PA_LAUNCH(gather_u8_kernel, grid2(dst_w, dst_h), dim3(256), 0, stream, (const uint8_t*)src, src_w, (uint8_t*)dst, dst_w, channels,
-              (const int*)ytab, (const int*)xtab);
-    LAUNCH_CHECK();
+    return pa_gather_u8_box(src, (int64_t)src_w * channels, src_h, src_w, dst, dst_h, dst_w, channels, ytab, xtab, stream);
 }
 
 int pa_seggpt_stitch(const void* prompts, const void* targets, const void* target_div, const void* query, float* imgs,

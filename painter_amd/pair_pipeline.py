@@ -1,0 +1,284 @@
+"""Painter's training input pipeline with the pixel work on the MI355X.
+
+The reference builds each sample in a DataLoader worker (Painter/data/pairdataset.py:106-190 `PairDataset.__getitem__` under the
+transform stack of Painter/main_train.py:232-251, classes in Painter/data/pair_transforms.py): decode two (image, target) pairs,
+RandomResizedCrop each to 448 x 448 (PIL BICUBIC / NEAREST per side), ColorJitter the image with probability 0.8, random horizontal
+flip, ToTensor, Normalize, stack the second pair under the first, optionally RandomResizedCrop the float canvases once more, derive
+`valid`, draw the patch mask.  Here file decode and the drawing of the random parameters stay on the host -- a handful of scalars per
+sample, from the same generators the reference uses -- and everything that touches pixels is a kernel (csrc/seggpt_io.hip resize
+passes, csrc/pair_io.hip), batched over the samples of a step and bit-identical to PIL / torch on the same parameters
+(tests/test_pair_pipeline_gpu.py).  The outputs are the model's inputs, already resident: `imgs`, `tgts`, `valid` float32
+[B][3][896][448].
+
+`SampleSpec` mirrors what `__getitem__` decides per sample; `sample_*` restate torchvision's parameter draws (torchvision is absent
+from this image, so those few lines are NOT pinned -- in a deployment with torchvision call its own get_params and fill the spec).
+There is no CPU fallback.
+"""
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import resample as RS
+from ._lib import check, lib
+
+BRIGHTNESS, CONTRAST, SATURATION, HUE = 0, 1, 2, 3
+VALID_NONE, VALID_LESS_ZERO, VALID_POSE, VALID_FG_ONLY = 0, 1, 2, 3
+MEAN = (0.485, 0.456, 0.406)
+STD = (0.229, 0.224, 0.225)
+
+
+@dataclass
+class PairSpec:
+    """One (image, target) pair of a sample and the random decisions of its transform stack."""
+    image: np.ndarray                                   # decoded RGB uint8 [H][W][3]
+    target: np.ndarray                                  # decoded RGB uint8 [H][W][3], same size
+    crop: Tuple[int, int, int, int]                     # RandomResizedCrop.get_params -> (top, left, height, width)
+    jitter_ops: Sequence[int] = ()                      # ColorJitter: ops in applied order (BRIGHTNESS ...), empty = not applied
+    jitter_factors: Sequence[float] = ()                # factor per op; for HUE the hue_factor in [-0.5, 0.5]
+    flip: bool = False
+
+
+@dataclass
+class SampleSpec:
+    """What PairDataset.__getitem__ decides for one sample (pairdataset.py:106-190)."""
+    pairs: List[PairSpec]                               # 1, or 2 with use_two_pairs
+    pair_type: str = ""                                 # selects the interpolation modes (:113-124) and the valid rule (:155-180)
+    seccrop: Optional[Tuple[int, int, int, int]] = None  # second RandomResizedCrop on the stitched canvases, or None
+    interpolation: Tuple[str, str] = field(default=None)
+
+    def __post_init__(self):
+        if self.interpolation is None:
+            self.interpolation = interpolation_modes(self.pair_type)
+
+
+def interpolation_modes(pair_type):
+    """pairdataset.py:113-124 -> (interpolation1 for images, interpolation2 for targets)."""
+    if "depth" in pair_type or "pose" in pair_type:
+        return "bicubic", "bicubic"
+    if "image2" in pair_type:
+        return "bicubic", "nearest"
+    if "2image" in pair_type:
+        return "nearest", "bicubic"
+    return "bicubic", "bicubic"
+
+
+def valid_rule(pair_type):
+    """pairdataset.py:155-180 -> (mode, black level before normalisation)."""
+    if "nyuv2_image2depth" in pair_type:
+        return VALID_LESS_ZERO, 1e-3 * 0.1
+    if "ade20k_image2semantic" in pair_type or "coco_image2panoptic_sem_seg" in pair_type:
+        return VALID_LESS_ZERO, 1e-5
+    if "image2pose" in pair_type:
+        return VALID_POSE, 1e-5
+    if "image2panoptic_inst" in pair_type:
+        return VALID_FG_ONLY, 1e-5
+    return VALID_NONE, 0.0
+
+
+def hue_shift_byte(hue_factor):
+    """torchvision's PIL adjust_hue adds uint8(hue_factor * 255) to the H plane with wrap-around."""
+    return int(hue_factor * 255) & 0xff
+
+
+# ------------------------------------------------------------------------------------------------ parameter draws (host, unpinned)
+def sample_resized_crop(height, width, scale, ratio=(3.0 / 4.0, 4.0 / 3.0)):
+    """torchvision RandomResizedCrop.get_params restated (torch global RNG): ten tries of a uniform area fraction and a log-uniform
+    aspect ratio, then the central fallback crop.  -> (top, left, h, w)."""
+    area = height * width
+    log_ratio = torch.log(torch.tensor(ratio))
+    for _ in range(10):
+        target_area = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
+        aspect_ratio = torch.exp(torch.empty(1).uniform_(log_ratio[0], log_ratio[1])).item()
+        w = int(round(math.sqrt(target_area * aspect_ratio)))
+        h = int(round(math.sqrt(target_area / aspect_ratio)))
+        if 0 < w <= width and 0 < h <= height:
+            i = torch.randint(0, height - h + 1, size=(1,)).item()
+            j = torch.randint(0, width - w + 1, size=(1,)).item()
+            return i, j, h, w
+    in_ratio = float(width) / float(height)
+    if in_ratio < min(ratio):
+        w = width
+        h = int(round(w / min(ratio)))
+    elif in_ratio > max(ratio):
+        h = height
+        w = int(round(h * max(ratio)))
+    else:
+        w, h = width, height
+    return (height - h) // 2, (width - w) // 2, h, w
+
+
+def sample_color_jitter(brightness=0.4, contrast=0.4, saturation=0.2, hue=0.1, p=0.8):
+    """RandomApply (pair_transforms.py:225-231) around torchvision ColorJitter.get_params restated (main_train.py:236-238 values):
+    -> (ops, factors), empty when the jitter is skipped."""
+    if p < torch.rand(1):
+        return (), ()
+    order = torch.randperm(4).tolist()
+    b = float(torch.empty(1).uniform_(max(0.0, 1 - brightness), 1 + brightness))
+    c = float(torch.empty(1).uniform_(max(0.0, 1 - contrast), 1 + contrast))
+    s = float(torch.empty(1).uniform_(max(0.0, 1 - saturation), 1 + saturation))
+    h = float(torch.empty(1).uniform_(-hue, hue))
+    f = {BRIGHTNESS: b, CONTRAST: c, SATURATION: s, HUE: h}
+    return tuple(order), tuple(f[o] for o in order)
+
+
+def sample_flip(p=0.5):
+    """pair_transforms.py:199-203."""
+    return bool(torch.rand(1) < p)
+
+
+# ------------------------------------------------------------------------------------------------ device pipeline
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class DevicePairPipeline:
+    """Builds the model inputs of a step on the device from `SampleSpec`s."""
+
+    def __init__(self, device, input_size=(896, 448)):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("painter_amd.pair_pipeline runs its pixel kernels on an MI355X only (no CPU fallback); got %s" % device)
+        self.H, self.W = input_size
+        self.side = input_size[1]                      # RandomResizedCrop(args.input_size[1]) -> side x side (main_train.py:234)
+        self._tables = {}
+
+    def _table(self, kind, in_size, out_size):
+        key = (kind, in_size, out_size)
+        t = self._tables.get(key)
+        if t is None:
+            if kind == "bicubic":
+                bounds, coeffs, ksize = RS.bicubic_tables(in_size, out_size)
+                t = (torch.from_numpy(bounds).to(self.device), torch.from_numpy(coeffs).to(self.device), ksize)
+            else:
+                t = torch.from_numpy(RS.pil_nearest_table(in_size, out_size)).to(self.device)
+            if len(self._tables) > 4096:               # crop sizes vary per sample: bound the cache
+                self._tables.clear()
+            self._tables[key] = t
+        return t
+
+    # ---- RandomResizedCrop on a decoded picture: PIL crop + resize
+    def resized_crop(self, picture, box, out, nearest):
+        """picture: uint8 [H][W][3] CUDA tensor; box = (top, left, h, w); out: uint8 [side][side][3] CUDA view written in place."""
+        assert picture.is_cuda and picture.dtype == torch.uint8 and picture.is_contiguous() and picture.shape[2] == 3
+        H, W, _ = picture.shape
+        i, j, h, w = box
+        assert 0 <= i and 0 <= j and h >= 1 and w >= 1 and i + h <= H and j + w <= W, (box, (H, W))
+        oh, ow = out.shape[0], out.shape[1]
+        row_bytes = W * 3
+        src = picture.data_ptr() + (i * W + j) * 3
+        if nearest:
+            if (h, w) == (oh, ow):                      # PIL returns a copy when the size does not change
+                out.copy_(picture[i:i + h, j:j + w])
+                return out
+            check(lib.pa_gather_u8_box(src, row_bytes, h, w, out.data_ptr(), oh, ow, 3, self._table("pil_nearest", h, oh).data_ptr(),
+                                       self._table("pil_nearest", w, ow).data_ptr(), _stream()), "pa_gather_u8_box")
+            return out
+        if w != ow and h != oh:
+            bounds, coeffs, ksize = self._table("bicubic", w, ow)
+            mid = torch.empty((h, ow, 3), dtype=torch.uint8, device=self.device)
+            check(lib.pa_resample_u8_box(src, row_bytes, h, w, mid.data_ptr(), h, ow, 3, bounds.data_ptr(), coeffs.data_ptr(), ksize, 0,
+                                         _stream()), "pa_resample_u8_box")
+            bounds, coeffs, ksize = self._table("bicubic", h, oh)
+            check(lib.pa_resample_u8_box(mid.data_ptr(), ow * 3, h, ow, out.data_ptr(), oh, ow, 3, bounds.data_ptr(), coeffs.data_ptr(), ksize, 1,
+                                         _stream()), "pa_resample_u8_box")
+        elif w != ow:
+            bounds, coeffs, ksize = self._table("bicubic", w, ow)
+            check(lib.pa_resample_u8_box(src, row_bytes, h, w, out.data_ptr(), oh, ow, 3, bounds.data_ptr(), coeffs.data_ptr(), ksize, 0,
+                                         _stream()), "pa_resample_u8_box")
+        elif h != oh:
+            bounds, coeffs, ksize = self._table("bicubic", h, oh)
+            check(lib.pa_resample_u8_box(src, row_bytes, h, w, out.data_ptr(), oh, ow, 3, bounds.data_ptr(), coeffs.data_ptr(), ksize, 1,
+                                         _stream()), "pa_resample_u8_box")
+        else:
+            out.copy_(picture[i:i + h, j:j + w])
+        return out
+
+    # ---- ColorJitter, batched, in place
+    def color_jitter(self, images, ops, factors):
+        """images: uint8 [B][h][w][3] CUDA; ops: int [B][4] (negative = none); factors: float [B][4] (HUE slot: hue_factor)."""
+        B, h, w, _ = images.shape
+        ops_h = np.full((B, 4), -1, np.int32)
+        fac_h = np.zeros((B, 4), np.float32)
+        for b in range(B):
+            for k, (o, f) in enumerate(zip(ops[b], factors[b])):
+                ops_h[b, k] = o
+                fac_h[b, k] = float(hue_shift_byte(f)) if o == HUE else np.float32(f)
+        if not (ops_h >= 0).any():
+            return images
+        ops_d = torch.from_numpy(ops_h).to(self.device)
+        fac_d = torch.from_numpy(fac_h).to(self.device)
+        ws = torch.empty(int(lib.pa_color_jitter_workspace_bytes(B)), dtype=torch.uint8, device=self.device)
+        check(lib.pa_color_jitter(images.data_ptr(), ops_d.data_ptr(), fac_d.data_ptr(), ops_h.ctypes.data, ws.data_ptr(), B, h, w, _stream()),
+              "pa_color_jitter")
+        return images
+
+    def to_tensor_normalize(self, images, flips, canvas, row0):
+        B, h, w, _ = images.shape
+        flip_d = torch.as_tensor([1 if f else 0 for f in flips], dtype=torch.int32).to(self.device)
+        check(lib.pa_to_tensor_normalize(images.data_ptr(), flip_d.data_ptr(), canvas.data_ptr(), B, h, w, canvas.shape[2], row0, _stream()),
+              "pa_to_tensor_normalize")
+        return canvas
+
+    def resized_crop_tensor(self, canvas, boxes, nearest):
+        """canvas: float32 [B][C][H][W]; boxes: [B][4] = (top, left, h, w) -> new canvas of the same shape."""
+        B, C, H, W = canvas.shape
+        out = torch.empty_like(canvas)
+        box_d = torch.as_tensor(np.asarray(boxes, np.int32).reshape(B, 4)).to(self.device)
+        check(lib.pa_resized_crop_f32(canvas.data_ptr(), out.data_ptr(), box_d.data_ptr(), B, C, H, W, 1 if nearest else 0, _stream()),
+              "pa_resized_crop_f32")
+        return out
+
+    def valid_map(self, tgts, pair_types):
+        B, C, H, W = tgts.shape
+        assert C == 3 and tgts.is_contiguous()
+        modes = np.zeros(B, np.int32)
+        thres = np.zeros((B, 3), np.float32)
+        mean, std = torch.tensor(MEAN), torch.tensor(STD)
+        for b, pt in enumerate(pair_types):
+            modes[b], level = valid_rule(pt)
+            thres[b] = ((torch.ones(3) * level - mean) / std).numpy()          # pairdataset.py:157-158, float32 on the host
+        valid = torch.empty_like(tgts)
+        ws = torch.empty(int(lib.pa_pair_valid_workspace_bytes(B)), dtype=torch.uint8, device=self.device)
+        check(lib.pa_pair_valid(tgts.data_ptr(), valid.data_ptr(), torch.from_numpy(modes).to(self.device).data_ptr(),
+                                torch.from_numpy(thres).to(self.device).data_ptr(), ws.data_ptr(), B, H * W, _stream()), "pa_pair_valid")
+        return valid
+
+    # ---- a whole step
+    def build_batch(self, samples: Sequence[SampleSpec]):
+        """-> (imgs, tgts, valid) float32 [B][3][H][W] on the device, what `collate(__getitem__ ...)` hands to the model."""
+        B = len(samples)
+        npairs = len(samples[0].pairs)
+        assert npairs in (1, 2) and all(len(s.pairs) == npairs for s in samples) and npairs * self.side == self.H, \
+            "input_size %s needs %d pair(s) of %d rows" % ((self.H, self.W), self.H // self.side, self.side)
+        imgs = torch.empty((B, 3, self.H, self.W), dtype=torch.float32, device=self.device)
+        tgts = torch.empty_like(imgs)
+        for k in range(npairs):
+            a = torch.empty((B, self.side, self.side, 3), dtype=torch.uint8, device=self.device)
+            t = torch.empty_like(a)
+            for b, s in enumerate(samples):
+                p = s.pairs[k]
+                pic = torch.from_numpy(np.ascontiguousarray(p.image)).to(self.device)
+                tpic = torch.from_numpy(np.ascontiguousarray(p.target)).to(self.device)
+                assert pic.shape == tpic.shape, "image and target of a pair share one crop box (pair_transforms.py:152-163)"
+                self.resized_crop(pic, p.crop, a[b], s.interpolation[0] == "nearest")
+                self.resized_crop(tpic, p.crop, t[b], s.interpolation[1] == "nearest")
+            self.color_jitter(a, [s.pairs[k].jitter_ops for s in samples], [s.pairs[k].jitter_factors for s in samples])
+            flips = [s.pairs[k].flip for s in samples]
+            self.to_tensor_normalize(a, flips, imgs, k * self.side)
+            self.to_tensor_normalize(t, flips, tgts, k * self.side)
+        # second crop: per sample either a box or the identity; both interpolation modes may occur in one batch
+        sec = [b for b, s in enumerate(samples) if s.seccrop is not None]
+        if sec:
+            boxes = [samples[b].seccrop if samples[b].seccrop is not None else (0, 0, self.H, self.W) for b in range(B)]
+            for canvas, side in ((imgs, 0), (tgts, 1)):
+                near = [samples[b].interpolation[side] == "nearest" for b in range(B)]
+                for mode in (False, True):
+                    idx = [b for b in sec if near[b] == mode]
+                    if idx:
+                        sel = torch.as_tensor(idx, device=self.device)
+                        canvas[sel] = self.resized_crop_tensor(canvas[sel].contiguous(), [boxes[b] for b in idx], mode)
+        valid = self.valid_map(tgts, [s.pair_type for s in samples])
+        return imgs, tgts, valid
