@@ -242,8 +242,10 @@ class DevicePairPipeline:
             thres[b] = ((torch.ones(3) * level - mean) / std).numpy()          # pairdataset.py:157-158, float32 on the host
         valid = torch.empty_like(tgts)
         ws = torch.empty(int(lib.pa_pair_valid_workspace_bytes(B)), dtype=torch.uint8, device=self.device)
-        check(lib.pa_pair_valid(tgts.data_ptr(), valid.data_ptr(), torch.from_numpy(modes).to(self.device).data_ptr(),
-                                torch.from_numpy(thres).to(self.device).data_ptr(), ws.data_ptr(), B, H * W, _stream()), "pa_pair_valid")
+        modes_d = torch.from_numpy(modes).to(self.device)          # named: a temporary would be recycled before the launch reads it
+        thres_d = torch.from_numpy(thres).to(self.device)
+        check(lib.pa_pair_valid(tgts.data_ptr(), valid.data_ptr(), modes_d.data_ptr(), thres_d.data_ptr(), ws.data_ptr(), B, H * W, _stream()),
+              "pa_pair_valid")
         return valid
 
     # ---- a whole step
