@@ -152,3 +152,32 @@ def load_reference_seggpt():
 def load_reference_seggpt_engine():
     """-> the reference module object of SegGPT/SegGPT_inference/seggpt_engine.py (cv2 is a stand-in: only inference_video needs it)."""
     return _load("ref_seggpt_engine", os.path.join(SEGGPT_DIR, "seggpt_engine.py"), SEGGPT_DIR)
+
+
+def load_reference_pairdataset():
+    """-> the reference module object of Painter/data/pairdataset.py.  It needs torchvision only for two base classes
+    (`VisionDataset`, `StandardTransform`, pairdataset.py:19); torchvision is absent from this image, so trivial stand-ins that keep
+    the constructor arguments are injected.  The transform objects handed to `PairDataset` by the tests are stand-ins as well."""
+    install_stubs()
+    if "torchvision" not in sys.modules:
+        class VisionDataset(torch.utils.data.Dataset):
+            def __init__(self, root=None, transforms=None, transform=None, target_transform=None):
+                self.root = root
+                self.transform = transform
+                self.target_transform = target_transform
+                self.transforms = transforms
+
+        class StandardTransform:
+            def __init__(self, transform=None, target_transform=None):
+                self.transform = transform
+                self.target_transform = target_transform
+
+        tv = _mod("torchvision", _painter_stub=True)
+        tv.datasets = _mod("torchvision.datasets")
+        tv.datasets.vision = _mod("torchvision.datasets.vision", VisionDataset=VisionDataset, StandardTransform=StandardTransform)
+    return _load("ref_pairdataset", os.path.join(PAINTER_DIR, "data", "pairdataset.py"), os.path.join(PAINTER_DIR, "data"))
+
+
+def load_reference_masking_generator():
+    """-> the reference module object of Painter/util/masking_generator.py (pure Python, no third-party imports)."""
+    return _load("ref_masking_generator", os.path.join(PAINTER_DIR, "util", "masking_generator.py"), os.path.join(PAINTER_DIR, "util"))
