@@ -128,3 +128,18 @@ def test_engine_module_mirrors_the_reference_interface():
         eng = ref_import.load_reference_seggpt_engine()
         for name in ("run_one_image", "inference_image", "inference_video"):
             assert list(inspect.signature(getattr(eng, name)).parameters) == list(inspect.signature(getattr(E, name)).parameters)
+
+
+@pytest.mark.skipif(not ref_import.reference_available(), reason="needs /root/reference (build container only)")
+def test_oracle_pipeline_on_the_references_example_pictures(tmp_path):
+    """the unmodified inference_image on the repository's own examples (JPEG pictures of several sizes, PNG targets), stand-in
+    network, against the oracle's composition -- real decoded pictures instead of the seeded synthetic ones."""
+    eng = ref_import.load_reference_seggpt_engine()
+    ex = os.path.join(ref_import.SEGGPT_DIR, "examples")
+    rgb = lambda name: np.array(Image.open(os.path.join(ex, name)).convert("RGB"))          # noqa: E731
+    for query, prompts in (("hmbb_3.jpg", ["hmbb_1", "hmbb_2"]), ("video_3.jpg", ["video_1"])):
+        out_path = str(tmp_path / (query + ".png"))
+        eng.inference_image(C.StandInModel(), "cpu", os.path.join(ex, query), [os.path.join(ex, p + ".jpg") for p in prompts],
+                            [os.path.join(ex, p + "_target.png") for p in prompts], out_path)
+        _, _, _, out = C.oracle_inference_image(rgb(query), [rgb(p + ".jpg") for p in prompts], [rgb(p + "_target.png") for p in prompts])
+        assert np.array_equal(np.array(Image.open(out_path)), out), query

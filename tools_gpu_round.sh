@@ -14,4 +14,12 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpu
 python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w gpurun_out/roofline_traffic.json > gpurun_out/traffic.log 2>&1
 rm -f gpurun_out/pmc_f/*kernel_trace.csv gpurun_out/pmc_w/*kernel_trace.csv
 timeout 600 python tools/seggpt_bench.py > gpurun_out/seggpt.log 2>&1
-tail -5 gpurun_out/tests.log; tail -3 gpurun_out/smoke.log; tail -3 gpurun_out/bench.log; tail -2 gpurun_out/seggpt.log
+# per-frame pre+post processing, end-to-end video loop, one step's input batch; kernel trace of both
+timeout 120 python tools/seggpt_io_bench.py > gpurun_out/n3_bench.json 2>/dev/null
+timeout 180 python tools/seggpt_video_bench.py > gpurun_out/n3_video.json 2>/dev/null
+timeout 120 python tools/pair_pipeline_bench.py > gpurun_out/n2_bench.json 2>/dev/null
+rm -rf gpurun_out/n3_prof gpurun_out/n2_prof
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/n3_prof -o n3 -- python tools/seggpt_io_bench.py --iters 20 --cpu-iters 1 > gpurun_out/n3_prof.log 2>&1
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/n2_prof -o n2 -- python tools/pair_pipeline_bench.py --iters 10 --cpu-iters 1 > gpurun_out/n2_prof.log 2>&1
+rm -f gpurun_out/n3_prof/*kernel_trace.csv gpurun_out/n2_prof/*kernel_trace.csv
+tail -5 gpurun_out/tests.log; tail -3 gpurun_out/smoke.log; tail -3 gpurun_out/bench.log; tail -2 gpurun_out/seggpt.log; cat gpurun_out/n3_bench.json gpurun_out/n3_video.json gpurun_out/n2_bench.json
