@@ -79,15 +79,22 @@ int pa_relpos_rows_padded(int Hp, int Wp);
 /* rcat: T [pa_relpos_rows_padded, 64] = [rel_pos_h ; rel_pos_w ; 0] */
 int pa_relpos_pack(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcat, int Hp, int Wp,
                    hipStream_t stream);
-/* qkv: T [batch*L, 3*heads*64] as produced by the qkv Linear; out: T [batch*L, heads*64]; lse: f32 [batch*heads, L] */
-int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse, int batch,
-                int L, int heads, int Hp, int Wp, float scale, hipStream_t stream);
+/* qkv: T [batch*L, 3*heads*64] as produced by the qkv Linear; out: T [batch*L, heads*64]; lse: f32 [batch*heads, L].
+ * tables: NULL (inference), or pa_attn_tables_bytes() of device memory that receives the per-query bias tables the
+ * backward reuses (only the 28-token-wide bf16 kernels write it; the size is 0 for every other case). */
+int64_t pa_attn_tables_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp);
+/* 0 = newest kernels that cover the grid (default), 2 = never use the 28-token-wide generation-3 kernels (diagnostics, A/B) */
+int pa_attn_set_generation(int generation);
+int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse,
+                void* tables, int batch, int L, int heads, int Hp, int Wp, float scale, hipStream_t stream);
 
 /* autograd of pa_attn_fwd (no reference source: torch autograd of the lines above).
  *   delta  : f32 [batch*heads, L] = rowsum(dO o O)                      (pa_attn_bwd_delta)
  *   dqkv   : T, same layout as qkv (dq | dk | dv)
  *   dG     : T [batch*L, heads*NRP] r-space bias gradient, consumed by pa_attn_bwd_relpos
  *   aux    : scratch of pa_attn_bwd_aux_bytes()
+ *   tables : what pa_attn_fwd wrote (NULL: the backward recomputes the bias tables itself, generation-2 kernels);
+ *            the backward adds lse / delta fields to it
  *   rcatT  : T [64, NRP] from pa_relpos_pack_t
  *   drcat  : f32 [NRP, 64] = [d rel_pos_h ; d rel_pos_w ; 0], overwritten */
 int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcatT, int Hp, int Wp,
@@ -96,8 +103,8 @@ int pa_attn_bwd_delta(int dtype, const void* out, int64_t ldo, const void* dout,
                       int L, int heads, hipStream_t stream);
 int64_t pa_attn_bwd_aux_bytes(int batch, int L, int heads, int Hp, int Wp);
 int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, const void* rcatT, const void* dout,
-                int64_t lddo, const float* lse, const float* delta, void* dqkv, void* dG, void* aux, int batch, int L,
-                int heads, int Hp, int Wp, float scale, hipStream_t stream);
+                int64_t lddo, const float* lse, const float* delta, void* dqkv, void* dG, void* aux, void* tables,
+                int batch, int L, int heads, int Hp, int Wp, float scale, hipStream_t stream);
 int64_t pa_attn_bwd_relpos_workspace_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp);
 int pa_attn_bwd_relpos(int dtype, const void* dG, const void* qkv, int64_t ldq, float* drcat, void* workspace,
                        int batch, int L, int heads, int Hp, int Wp, hipStream_t stream);

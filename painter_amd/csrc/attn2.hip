@@ -19,102 +19,15 @@
 // Work split (all three): workgroup = 4 waves, wave = 32 rows (queries, or keys in dKV), lane = one row end to end;
 // 32-row tiles of the other axis stream through LDS, register-staged (global -> VGPR early, VGPR -> LDS late); STAGES = 2
 // double-buffers them (one barrier per tile), STAGES = 1 trades the second stage for one more resident workgroup.
-#include "attn_common.h"
+#include "attn_tile.h"
 #include "../../include/painter_hip.h"
 #include "attn2.h"
 #include <cstdlib>
 
 namespace a2 {
+using namespace atile;
 
-constexpr int NW = 4, NT = 256, ROWS = 128, IMG = 4096, STAGE_QK = 2 * IMG;
 constexpr float THR = 6.0f;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
-
-// 1-D grid of (row blocks per head) x (batch * heads) workgroups.  Workgroup n runs on XCD n % 8 (MI355X dispatch order), and each
-// XCD has its own 4 MB L2: give every XCD a contiguous run of (head, row block) pairs, row block fastest, so that all row blocks
-// of a head stream the head's K/V (or Q/dO/aux) tiles through ONE L2 instead of eight (7-8 heads x 0.4 MB live per XCD).
-// PA_ATTN_XCD=0 (diagnostics) keeps the plain order.
-DEVI void wg_coords(int nblk, int xcd_map, int& blk, int& bh) {
-    const int n = blockIdx.x, total = gridDim.x;
-    int v = n;
-    if (xcd_map) {
-        const int xq = total >> 3, xr = total & 7, xcd = n & 7;
-        v = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (n >> 3);
-    }
-    bh = v / nblk;
-    blk = v - bh * nblk;
-}
-
-// ---- tile image: 32 rows x 128 B, 16-B chunk index XORed with a bijection of row bits 1..3
-DEVI int vsw(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
-
-struct Stager {   // one 32 x 64 bf16 tile, 256 threads, one 16-B chunk each
-    uint4 r;
-    DEVI void load(const bf16* src, size_t ld, int tid) { r = *reinterpret_cast<const uint4*>(src + (size_t)(tid >> 3) * ld + (tid & 7) * 8); }
-    DEVI void store(unsigned char* img, int tid) const {
-        const int row = tid >> 3, c = tid & 7;
-        *reinterpret_cast<uint4*>(img + row * 128 + ((c ^ vsw(row)) << 4)) = r;
-    }
-};
-
-// per-lane address pieces, computed once
-struct LaneAddr {
-    int rowbase, t;          // row fragment: byte = rowbase + (((2 s) ^ t) << 4)
-    int tr[2][2];            // transposed fragment: [dblk][lo/hi] byte offset for k-step 0; k-step 1 = + 2048
-    DEVI void init(int lane) {
-        const int row = lane & 31, g = lane >> 5;
-        rowbase = row * 128;
-        t = vsw(row) ^ g;
-        const int i = lane & 15, half = (lane >> 4) & 1;
-#pragma unroll
-        for (int db = 0; db < 2; ++db)
-#pragma unroll
-            for (int hi = 0; hi < 2; ++hi) {
-                const int r = 4 * g + (i >> 2) + 8 * hi;
-                const int chunk = 4 * db + 2 * half + ((i & 3) >> 1);
-                tr[db][hi] = r * 128 + ((chunk ^ vsw(r)) << 4) + (i & 1) * 8;
-            }
-    }
-};
-// A operand, rows = tile rows, contraction over d (k-step s of 16)
-DEVI bf16x8 rowfrag(const unsigned char* img, const LaneAddr& a, int s) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + a.rowbase + (((2 * s) ^ a.t) << 4)));
-}
-// A operand, rows = d (block db of 32), contraction over the tile's rows: slot t <-> row 16 s + 4 g + (t & 3) + 8 (t >> 2),
-// the order in which the MFMA D layout hands a lane its values (so D registers pack straight into the B operand)
-DEVI bf16x8 trfrag(const unsigned char* img, const LaneAddr& a, int db, int s) {
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a.tr[db][0] + s * 2048));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(img + a.tr[db][1] + s * 2048));
-    const u32x2 l = __builtin_bit_cast(u32x2, lo), h = __builtin_bit_cast(u32x2, hi);
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(l, h, 0, 1, 2, 3));
-}
-DEVI bf16x8 gfrag(const bf16* p, int s, int g) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p + 16 * s + 8 * g)); }
-typedef __attribute__((ext_vector_type(8))) float f32x8;
-DEVI bf16x8 packfrag(const float* v) {      // one v_cvt_pk_bf16_f32 per pair
-    const f32x8 f = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
-    return __builtin_convertvector(f, bf16x8);
-}
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-// exchange with the lane 32 away (the other half of this row's key runs): VALU permlane, no LDS round trip
-DEVI float xor32(float v) {
-    const uint32_t u = __builtin_bit_cast(uint32_t, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (threadIdx.x & 32) ? r[0] : r[1]);
-}
-DEVI float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
-DEVI float max16(const float* p) {
-    const float a = max3f(p[0], p[1], p[2]), b = max3f(p[3], p[4], p[5]), c = max3f(p[6], p[7], p[8]), d = max3f(p[9], p[10], p[11]),
-                e = max3f(p[12], p[13], p[14]);
-    return max3f(max3f(a, b, c), max3f(d, e, p[15]), -INFINITY);
-}
-DEVI float sum16(const float* p) {      // packed adds
-    f32x2 a = {p[0], p[1]}, b = {p[2], p[3]}, c = {p[4], p[5]}, d = {p[6], p[7]};
-    a += f32x2{p[8], p[9]}; b += f32x2{p[10], p[11]}; c += f32x2{p[12], p[13]}; d += f32x2{p[14], p[15]};
-    a += b; c += d; a += c;
-    return a[0] + a[1];
-}
 // run table: for tile phase ph, half-wave g, run rg: low 16 bits = kw * 4 (byte offset into the lane's kw table row),
 // high 16 bits = (kh - kh0(tile)) * 2 (byte offset into the kh table row, relative to the tile's first key row)
 DEVI void build_rtab(uint32_t* rtab, int nphase, int Wp, int tid) {
@@ -124,7 +37,6 @@ DEVI void build_rtab(uint32_t* rtab, int nphase, int Wp, int tid) {
         rtab[tid] = (uint32_t)((a % Wp) * 4) | ((uint32_t)((a / Wp) * 2) << 16);
     }
 }
-DEVI f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 DEVI float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
 DEVI float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
 
@@ -152,26 +64,6 @@ DEVI void build_tables(float* tw, bf16* th, const bf16* rcat, int NRP, const bf1
                 if (rr < 2 * Wp - 1 && kw >= 0 && kw < Wp) tw[kw] = acc[reg] * inv_scale;
             }
         }
-    }
-}
-
-// stage a wave's [d][row] accumulators (2 blocks of 32 d) as bf16 rows in LDS, then write whole 128-B rows
-DEVI void stage_rows(unsigned char* stg, const f32x16 (&acc)[2], float mul, int lane) {
-    const int g = lane >> 5;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int d0 = db * 32 + 8 * rg + 4 * g;
-            *reinterpret_cast<uint2*>(stg + (lane & 31) * 128 + d0 * 2) =
-                make_uint2(pack_bf16x2(acc[db][rg * 4] * mul, acc[db][rg * 4 + 1] * mul), pack_bf16x2(acc[db][rg * 4 + 2] * mul, acc[db][rg * 4 + 3] * mul));
-        }
-}
-DEVI void write_rows(const unsigned char* stg, bf16* dst, size_t ld, int lane) {   // dst = row 0 of the wave's 32 rows
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = lane + 64 * i, row = c >> 3, ch = c & 7;
-        *reinterpret_cast<uint4*>(dst + (size_t)row * ld + ch * 8) = *reinterpret_cast<const uint4*>(stg + row * 128 + ch * 16);
     }
 }
 
@@ -438,10 +330,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
                 for (int e = 0; e < 4; ++e) ds[rg * 4 + e] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + e], sl, bhx));
             }
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 t = f32x2{ds[r], ds[r + 1]} * f32x2{dpacc[r], dpacc[r + 1]};
-                ds[r] = t[0]; ds[r + 1] = t[1];
-            }
+            for (int r = 0; r < 16; ++r) ds[r] *= dpacc[r];
             const bf16x8 dsf0 = packfrag(ds), dsf1 = packfrag(ds + 8);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
@@ -615,10 +504,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
                 p[rg * 4 + 3] = __builtin_amdgcn_exp2f(fmaf(sacc[rg * 4 + 3], sl, b4.w));
             }
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 t = f32x2{p[r], p[r + 1]} * f32x2{dpacc[r], dpacc[r + 1]};
-                ds[r] = t[0]; ds[r + 1] = t[1];
-            }
+            for (int r = 0; r < 16; ++r) ds[r] = p[r] * dpacc[r];
             const bf16x8 pf0 = packfrag(p), pf1 = packfrag(p + 8), dsf0 = packfrag(ds), dsf1 = packfrag(ds + 8);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
@@ -639,15 +525,6 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
         write_rows(stg, orow + D, ldq, lane);
         write_rows(stg + IMG, orow + 2 * D, ldq, lane);
     }
-}
-
-static int set_smem(const void* kern, bool& done) {
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return (int)e;
-        done = true;
-    }
-    return 0;
 }
 
 }   // namespace a2

@@ -1,0 +1,11 @@
+// entry points of the third-generation bf16 attention kernels (attn3.hip: key rows of 28 tokens, i.e. the 896x448 / patch 16 grid),
+// used by pa_attn_fwd / pa_attn_bwd
+#pragma once
+#include "common.h"
+bool attn3_ok(int L, int Hp, int Wp);
+// per-(sample, head, 32-query tile) table tiles written by the forward and read by the backward; 0 when attn3_ok() is false
+int64_t attn3_table_bytes(int Bn, int L, int H, int Hp, int Wp);
+int attn3_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t ldo, float* lse, void* tables, int Bn, int L, int H,
+              int Hp, int Wp, float scale, hipStream_t st);
+int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const float* delta,
+              void* tables, bf16* dqkv, bf16* dG, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st);

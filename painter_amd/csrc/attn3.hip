@@ -1,0 +1,717 @@
+// bf16 fused attention with decomposed rel-pos bias, third generation: forward, backward-dQ, backward-dKV for token grids whose key
+// rows are 28 tokens wide (the 896x448 / patch-16 grid of every reference factory: Painter/models_painter.py:476-487,
+// SegGPT_inference/models_seggpt.py).  Same math and C ABI as attn2.hip (Painter/models_painter.py:76-86, util/vitdet_utils.py:63-125,
+// SURVEY.md 8a a5-a8, a17, Appendix B.2); attn2.hip keeps the other grids, attn_fwd.hip / attn_bwd.hip the exact-fp32 build.
+//
+// Why a third generation.  PMC of attn2 (round 1): the VALU, not the matrix pipe, is the busy unit (per 32x32 tile and wave ~700 VALU
+// cycles against 256-512 MFMA cycles) and waves sit ~45 % of their cycles in s_waitcnt/barrier.  A good part of the VALU stream and
+// the dependent LDS reads (run table -> kw table -> kh table) only served the rel-pos bias.  Here the bias costs no VALU at all:
+//
+//   S[q][key] = q.k + sum_j T[q][j] E[key][j]          one extra 32-deep contraction = 2 MFMAs per 32x32 tile
+//
+//   T[q][j]  (bf16, per query):   28 entries  tw[q][kw]  = (q . rel_pos_w[qw - kw + 27]) / scale
+//                                  4 entries  "window"   = (q . rel_pos_h[qh - kh + Hp-1]) / scale  of the <= 2 key rows a tile touches
+//   E[key][j] (one-hot, bf16):    1 at j = kw(key) and at the window slot (kh(key) & 3)
+//
+// 7 key tiles of 32 = 8 key rows of 28: the one-hot patterns repeat with period 7 (7 images of 2 KB in LDS), the loop is unrolled over
+// the 7 phases so every offset is an immediate, tile p of a period touches key rows p and p+1, and a key row r lives in window slot
+// r & 3.  The four window slots sit in ONE VGPR pair position of the T operand (slots (t = 6, 7) of both half-waves), so moving the
+// window forward is one 16-bit LDS read per tile, for all lanes alike.  The bias GRADIENT is the transposed contraction
+// dT[j][q] += E^T[j][key] dS^T[key][q] (2 MFMAs, the same LDS image read with the transposing ds_read_b64_tr_b16): rows of kw
+// accumulate over all tiles, a window row is complete after the tile that bears its number and is written back as bf16 into the kh
+// table entry it replaces.  In dKV (lane = key, registers = queries) the row log-sum-exp rides in the two window slots the wave's two
+// key rows leave free, as a bf16 hi + lo pair against E = 1, so S - lse also comes out of the matrix pipe.
+// Per 32x32 tile and wave: forward 10 MFMAs / ~75 VALU (was 8 / ~115), dQ 16 / ~65 (14 / ~130), dKV 18 / ~70 (16 / ~100).
+//
+// Table tiles.  The forward builds T once per query (G = Rcat . Q^T on the matrix pipe, as before) and, when a backward will follow,
+// writes it to `tables`: per (sample, head, 32-query tile) a block of
+//     [32 q][32 slots] bf16 kw part (window slots zero) | [Hp + 2][32 q] bf16 kh part, transposed; rows Hp, Hp+1 = -lse/scale hi, lo
+//     | [32 q] f32 -Delta                                                          (rounded up to 256 B; 6 KB at Hp = 56)
+// The backward's prep kernel fills the lse rows and -Delta; dQ reads its own rows once, dKV streams the kw part and the <= 8 kh rows
+// its workgroup needs with every query tile (10.7 KB per tile instead of attn2's 19 KB).  Because forward and backward contract the
+// very same bf16 T entries, P is recomputed in the backward from exactly the logits the forward saw.
+#include "attn_tile.h"
+#include "../../include/painter_hip.h"
+#include "attn3.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace a3 {
+using namespace atile;
+
+constexpr int WP = 28, PH = 7, RPP = 8;       // key-row width; 32-key tile phases per period; key rows per period (7 * 32 = 8 * 28)
+constexpr int EIMG = 2048;                    // one one-hot image: [32 keys][32 slots] bf16
+constexpr float THR = 6.0f;
+
+__host__ __device__ inline int ttile_bytes(int Hp) { return (2048 + (Hp + 2) * 64 + 128 + 255) & ~255; }
+// physical slot of kw inside a 32-slot T row / E row: k-step 0 = kw 0..15; k-step 1: half-wave g holds kw 16+6g .. 21+6g in t = 0..5 and
+// the window slots 2g, 2g+1 in t = 6, 7
+DEVI int kw_phys(int kw) { return kw < 22 ? kw : kw + 2; }
+
+// one-hot images of the 7 tile phases.  Row i = key 32 p + i of a period: kw = (4 p + i) % 28, key row (relative) p + ((4 p + i) >= 28).
+// 16-byte chunk c = 2 s + g of a row is stored at c ^ ((i >> 2) & 3): conflict-free for the row reads (ds_read_b128) and for the
+// transposing reads (which always see 4 consecutive rows of one 4-row group).
+DEVI void build_eimg(unsigned char* eimg, int tid) {
+    for (int idx = tid; idx < PH * 512; idx += NT) {
+        const int ph = idx >> 9, i = (idx >> 4) & 31, dw = idx & 15;
+        const int c = dw >> 2, s = c >> 1, g = c & 1;
+        const int a = 4 * ph + i, kw = a % WP, khr = ph + (a >= WP ? 1 : 0);
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int t = (dw & 3) * 2 + e;
+            bool one;
+            if (s == 0) one = kw == 8 * g + t;
+            else if (t < 6) one = kw == 16 + 6 * g + t;
+            else one = (khr & 3) == 2 * g + (t - 6);
+            if (one) w |= 0x3F80u << (16 * e);
+        }
+        *reinterpret_cast<uint32_t*>(eimg + ph * EIMG + i * 64 + ((c ^ ((i >> 2) & 3)) << 4) + (dw & 3) * 4) = w;
+    }
+}
+struct EAddr {
+    int row[2];    // [32 rows][64 B] image, chunk-swizzled as above: 16-byte row fragment of k-step s (lane = row)
+    int tr[2];     // transposed fragment (rows = slots, contraction over the image's rows): lo / hi; k-step 1 = + 1024
+    DEVI void init(int lane) {
+        const int i = lane & 31, g = lane >> 5;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) row[s] = i * 64 + (((2 * s + g) ^ ((i >> 2) & 3)) << 4);
+        const int ii = lane & 15, half = (lane >> 4) & 1;
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const int r = 4 * g + (ii >> 2) + 8 * hi;
+            tr[hi] = r * 64 + (((2 * half + ((ii & 3) >> 1)) ^ ((r >> 2) & 3)) << 4) + (ii & 1) * 8;
+        }
+    }
+};
+DEVI bf16x8 efrag(const unsigned char* img, const EAddr& e, int s) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + e.row[s]));
+}
+DEVI bf16x8 etrfrag(const unsigned char* img, const EAddr& e, int s) {
+    const u32x2 l = ldtr(img + e.tr[0] + s * 1024), h = ldtr(img + e.tr[1] + s * 1024);
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(l, h, 0, 1, 2, 3));
+}
+DEVI bf16x8 as_frag(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
+DEVI f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+// window slot update: 16 bits of `w` <- the kh-table entry at p (every lane of the wave, see the file header)
+template <int HALF> DEVI void win_set(uint32_t& w, const unsigned char* p) {
+    const uint32_t v = *reinterpret_cast<const uint16_t*>(p);
+    w = HALF ? ((w & 0xffffu) | (v << 16)) : ((w & 0xffff0000u) | v);
+}
+// eacc register (half-wave 1) that holds window slot `slot`: rows 22, 23, 30, 31 of the D tile
+DEVI constexpr int win_reg(int slot) { return slot == 0 ? 10 : slot == 1 ? 11 : slot == 2 ? 14 : 15; }
+
+// T of this lane's query row from G^T = Rcat . Q^T: kw part -> twimg[q][32 slots] (bf16, window slots stay zero),
+// kh part -> thT[kh][q] (bf16).  Both scaled by 1 / scale, so that logits = scale * log2e * (q.k + T.E).
+DEVI void build_tables3(unsigned char* twimg, unsigned char* thT, const bf16* rcat, int NRP, const bf16x8 (&qf)[4], int qh, int qw, int Hp,
+                        float inv_scale, int lane) {
+    const int g = lane >> 5, ql = lane & 31;
+    *reinterpret_cast<uint4*>(twimg + lane * 32) = zero4();
+    *reinterpret_cast<uint4*>(twimg + lane * 32 + 16) = zero4();
+    for (int rbk = 0; rbk < NRP / 32; ++rbk) {
+        f32x16 acc = zero16();
+        const bf16* rp = rcat + (size_t)(rbk * 32 + ql) * ATT_HD;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma(gfrag(rp, s, g), qf[s], acc);
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int r = rbk * 32 + acc_row(reg, lane);
+            const bf16 v = (bf16)(acc[reg] * inv_scale);
+            if (r < 2 * Hp - 1) {
+                const int kh = qh + Hp - 1 - r;
+                if (kh >= 0 && kh < Hp) *reinterpret_cast<bf16*>(thT + kh * 64 + ql * 2) = v;
+            } else {
+                const int rr = r - (2 * Hp - 1);
+                const int kw = qw + WP - 1 - rr;
+                if (rr < 2 * WP - 1 && kw >= 0 && kw < WP) *reinterpret_cast<bf16*>(twimg + ql * 64 + kw_phys(kw) * 2) = v;
+            }
+        }
+    }
+}
+
+// =============================================================================================== forward
+// LDS: [K img | V img] x STAGES | thT 4 waves x [Hp][32 q] bf16 | 7 one-hot images (the per-wave T rows alias them during the prologue)
+template <int STAGES>
+__global__ __launch_bounds__(NT, STAGES == 1 ? 4 : 2) void fwd_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
+                                                                      bf16* __restrict__ out, size_t ldo, float* __restrict__ lse,
+                                                                      unsigned char* __restrict__ tables, int L, int H, int Hp, int NRP,
+                                                                      float scale, int nblk, int xcd_map) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, ql = lane & 31;
+    int blk, bh;
+    wg_coords(nblk, xcd_map, blk, bh);
+    const int b = bh / H, h = bh % H, D = H * ATT_HD;
+    const bf16* base = qkv + (size_t)b * L * ldq + h * ATT_HD;
+    const bf16* kbase = base + D;
+    const bf16* vbase = base + 2 * D;
+    const int qt = blk * NW + wave;
+    const bool valid = qt * 32 < L;
+    const int q = qt * 32 + ql;
+    unsigned char* thT = smem + STAGES * STAGE_QK + wave * Hp * 64;
+    unsigned char* eimg = smem + STAGES * STAGE_QK + NW * Hp * 64;
+    unsigned char* twimg = eimg + wave * 2048;
+    LaneAddr la;
+    la.init(lane);
+    EAddr ea;
+    ea.init(lane);
+    const int ntile = L / 32;
+    Stager ks, vs;
+    ks.load(kbase, ldq, tid);
+    vs.load(vbase, ldq, tid);
+
+    bf16x8 qf[4];
+    uint4 T0 = zero4(), T1 = zero4();
+    if (valid) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) qf[s] = gfrag(base + (size_t)q * ldq, s, g);
+        build_tables3(twimg, thT, rcat, NRP, qf, q / WP, q % WP, Hp, 1.f / scale, lane);
+        T0 = *reinterpret_cast<const uint4*>(twimg + ql * 64 + 16 * g);          // same-wave LDS ops are ordered
+        T1 = *reinterpret_cast<const uint4*>(twimg + ql * 64 + 32 + 16 * g);
+        if (tables != nullptr) {
+            unsigned char* tt = tables + ((size_t)bh * ntile + qt) * ttile_bytes(Hp);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<uint4*>(tt + (lane + 64 * i) * 16) = *reinterpret_cast<const uint4*>(twimg + (lane + 64 * i) * 16);
+            for (int c = lane; c < Hp * 4; c += 64) *reinterpret_cast<uint4*>(tt + 2048 + c * 16) = *reinterpret_cast<const uint4*>(thT + c * 16);
+        }
+    }
+    __syncthreads();                    // the T rows in the image region are dead
+    build_eimg(eimg, tid);
+    ks.store(smem, tid);
+    vs.store(smem + IMG, tid);
+    __syncthreads();
+
+    f32x16 oacc[2];
+    oacc[0] = zero16();
+    oacc[1] = zero16();
+    float m = 0.f, l = 0.f;
+    const float sl = scale * LOG2E_F;
+    const unsigned char* thw = thT + ql * 2;
+
+    auto body = [&](auto pc, int a) {
+        constexpr int P = decltype(pc)::value;
+        const int j = a * PH + P;
+        {   // unconditional (clamped to the last tile): a static number of loads in flight
+            const int jn = min(j + 1, ntile - 1);
+            ks.load(kbase + (size_t)jn * 32 * ldq, ldq, tid);
+            vs.load(vbase + (size_t)jn * 32 * ldq, ldq, tid);
+        }
+        const unsigned char* kimg = smem + (STAGES == 2 ? (j & 1) * STAGE_QK : 0);
+        const unsigned char* vimg = kimg + IMG;
+        if (valid) {
+            const unsigned char* thr = thw + a * (RPP * 64);
+            if constexpr (P == 0) win_set<0>(T1.w, thr);
+            win_set<(P + 1) & 1>(T1.w, thr + (P + 1) * 64);
+            const unsigned char* ei = eimg + P * EIMG;
+            // every operand fragment of the S chain is requested before the first MFMA (the scheduler otherwise alternates
+            // read - wait - MFMA through one register quad and pays the LDS latency six times per tile)
+            const bf16x8 ef0 = efrag(ei, ea, 0), ef1 = efrag(ei, ea, 1);
+            bf16x8 kfr[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kfr[s] = rowfrag(kimg, la, s);
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 sacc = zero16();
+            sacc = mfma(ef0, as_frag(T0), sacc);
+            sacc = mfma(ef1, as_frag(T1), sacc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) sacc = mfma(kfr[s], qf[s], sacc);
+            // V fragments travel while the softmax runs on the VALU (the 128-register single-stage build has room for half of them)
+            bf16x8 vtr[2][2];
+            vtr[0][0] = trfrag(vimg, la, 0, 0);
+            vtr[0][1] = trfrag(vimg, la, 0, 1);
+            if constexpr (STAGES == 2) { vtr[1][0] = trfrag(vimg, la, 1, 0); vtr[1][1] = trfrag(vimg, la, 1, 1); }
+            __builtin_amdgcn_sched_barrier(0);
+            float p[16];
+            const float nm = -m;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = fmaf(sacc[r], sl, nm);
+            float tmax = max16(p);
+            tmax = fmaxf(tmax, xor32(tmax));
+            if (j == 0 || __any(tmax > THR)) {          // wave-uniform; after the first tiles almost never taken
+                const float delta = (j == 0) ? tmax : fmaxf(tmax, 0.f);
+                const float alpha = __builtin_amdgcn_exp2f(-delta);
+                m += delta;
+                l *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; p[r] -= delta; }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = __builtin_amdgcn_exp2f(p[r]);
+            l += sum16(p);
+            const bf16x8 pf0 = packfrag(p), pf1 = packfrag(p + 8);
+            if constexpr (STAGES == 1) { vtr[1][0] = trfrag(vimg, la, 1, 0); vtr[1][1] = trfrag(vimg, la, 1, 1); }
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                oacc[db] = mfma(vtr[db][0], pf0, oacc[db]);
+                oacc[db] = mfma(vtr[db][1], pf1, oacc[db]);
+            }
+        }
+        if constexpr (STAGES == 1) __syncthreads();      // every wave has finished reading the only stage
+        if (j + 1 < ntile) {
+            ks.store(smem + (STAGES == 2 ? ((j + 1) & 1) * STAGE_QK : 0), tid);
+            vs.store(smem + (STAGES == 2 ? ((j + 1) & 1) * STAGE_QK : 0) + IMG, tid);
+        }
+        __syncthreads();
+    };
+    for (int a = 0; a < Hp / RPP; ++a) {
+        body(std::integral_constant<int, 0>{}, a);
+        body(std::integral_constant<int, 1>{}, a);
+        body(std::integral_constant<int, 2>{}, a);
+        body(std::integral_constant<int, 3>{}, a);
+        body(std::integral_constant<int, 4>{}, a);
+        body(std::integral_constant<int, 5>{}, a);
+        body(std::integral_constant<int, 6>{}, a);
+    }
+    // per-wave 4 KB staging tile: the K/V stages (2 stages) or, with the single stage, the one-hot images -- both are free now
+    unsigned char* stg = smem + wave * IMG;
+    if constexpr (STAGES == 1) { if (wave >= 2) stg = eimg + (wave - 2) * IMG; }
+    if (valid) {
+        const float lt = l + xor32(l);
+        if (g == 0) lse[(size_t)bh * L + q] = (m + __builtin_amdgcn_logf(lt)) * LN2_F;
+        stage_rows(stg, oacc, 1.f / lt, lane);
+        write_rows(stg, out + (size_t)(b * L + qt * 32) * ldo + h * ATT_HD, ldo, lane);   // same-wave LDS ops are ordered
+    }
+}
+
+// =============================================================================================== backward: dQ, bias gradients
+// LDS: [K img | V img] x 2 | thT 4 waves x [Hp][32 q] bf16 (values, replaced row by row by their gradients) | 7 one-hot images
+// NDL = true keeps -Delta in 16 accumulator-init registers (dP - Delta comes out of the MFMA chain); false adds it on the VALU
+template <int MINW, bool NDL>
+__global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcatT,
+                                                          const bf16* __restrict__ dout, size_t lddo, const float* __restrict__ lse,
+                                                          const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv,
+                                                          bf16* __restrict__ dG, int L, int H, int Hp, int NRP, float scale, int nblk,
+                                                          int xcd_map) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, ql = lane & 31;
+    int blk, bh;
+    wg_coords(nblk, xcd_map, blk, bh);
+    const int b = bh / H, h = bh % H, D = H * ATT_HD;
+    const bf16* base = qkv + (size_t)b * L * ldq + h * ATT_HD;
+    const bf16* kbase = base + D;
+    const bf16* vbase = base + 2 * D;
+    const int qt = blk * NW + wave;
+    const bool valid = qt * 32 < L;
+    const int q = qt * 32 + ql;
+    const int qh = q / WP, qw = q % WP;
+    unsigned char* thT = smem + 2 * STAGE_QK + wave * Hp * 64;
+    unsigned char* eimg = smem + 2 * STAGE_QK + NW * Hp * 64;
+    LaneAddr la;
+    la.init(lane);
+    EAddr ea;
+    ea.init(lane);
+    const int ntile = L / 32;
+    const float sl = scale * LOG2E_F;
+    Stager ks, vs;
+    ks.load(kbase, ldq, tid);
+    vs.load(vbase, ldq, tid);
+    build_eimg(eimg, tid);
+
+    bf16x8 qf[4], dof[4];
+    uint4 T0 = zero4(), T1 = zero4();
+    float nlse2 = 0.f, ndlt = 0.f;
+    if (valid) {
+        const unsigned char* tt = tables + ((size_t)bh * ntile + qt) * ttile_bytes(Hp);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = gfrag(base + (size_t)q * ldq, s, g);
+            dof[s] = gfrag(dout + (size_t)(b * L + q) * lddo + h * ATT_HD, s, g);
+        }
+        T0 = *reinterpret_cast<const uint4*>(tt + ql * 64 + 16 * g);
+        T1 = *reinterpret_cast<const uint4*>(tt + ql * 64 + 32 + 16 * g);
+        for (int c = lane; c < Hp * 4; c += 64) *reinterpret_cast<uint4*>(thT + c * 16) = *reinterpret_cast<const uint4*>(tt + 2048 + c * 16);
+        nlse2 = -lse[(size_t)bh * L + q] * LOG2E_F;
+        ndlt = *reinterpret_cast<const float*>(tt + 2048 + (Hp + 2) * 64 + ql * 4);
+    }
+    f32x16 ndl;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ndl[r] = NDL ? ndlt : 0.f;
+    ks.store(smem, tid);
+    vs.store(smem + IMG, tid);
+    __syncthreads();
+
+    f32x16 dq[2], eacc;
+    dq[0] = zero16();
+    dq[1] = zero16();
+    eacc = zero16();
+    unsigned char* thw = thT + ql * 2;
+
+    auto body = [&](auto pc, int a) {
+        constexpr int P = decltype(pc)::value;
+        const int j = a * PH + P;
+        if (j + 1 < ntile) {
+            ks.load(kbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
+            vs.load(vbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
+        }
+        const unsigned char* kimg = smem + (j & 1) * STAGE_QK;
+        const unsigned char* vimg = kimg + IMG;
+        if (valid) {
+            unsigned char* thr = thw + a * (RPP * 64);
+            if constexpr (P == 0) win_set<0>(T1.w, thr);
+            win_set<(P + 1) & 1>(T1.w, thr + (P + 1) * 64);
+            const unsigned char* ei = eimg + P * EIMG;
+            // all ten operand fragments of the S and dP chains are requested before the first MFMA
+            const bf16x8 ef0 = efrag(ei, ea, 0), ef1 = efrag(ei, ea, 1);
+            bf16x8 kfr[4], vfr[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { vfr[s] = rowfrag(vimg, la, s); kfr[s] = rowfrag(kimg, la, s); }
+            __builtin_amdgcn_sched_barrier(0);
+            f32x16 sacc = zero16(), dpacc;
+            sacc = mfma(ef0, as_frag(T0), sacc);
+            dpacc = mfma(vfr[0], dof[0], ndl);
+            sacc = mfma(ef1, as_frag(T1), sacc);
+#pragma unroll
+            for (int s = 1; s < 4; ++s) dpacc = mfma(vfr[s], dof[s], dpacc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) sacc = mfma(kfr[s], qf[s], sacc);
+            // the transposed fragments of the second MFMA group travel while the VALU turns S, dP into dS
+            bf16x8 ktr[2][2], etr[2];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) { ktr[db][0] = trfrag(kimg, la, db, 0); ktr[db][1] = trfrag(kimg, la, db, 1); }
+            etr[0] = etrfrag(ei, ea, 0);
+            etr[1] = etrfrag(ei, ea, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sl, nlse2));
+                ds[r] = NDL ? pr * dpacc[r] : pr * (dpacc[r] + ndlt);
+            }
+            const bf16x8 dsf0 = packfrag(ds), dsf1 = packfrag(ds + 8);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                dq[db] = mfma(ktr[db][0], dsf0, dq[db]);
+                dq[db] = mfma(ktr[db][1], dsf1, dq[db]);
+            }
+            eacc = mfma(etr[0], dsf0, eacc);
+            eacc = mfma(etr[1], dsf1, eacc);
+            // key row 8 a + P is complete: its gradient (window slot P & 3 = a D row of half-wave 1) replaces the table entry
+            if (g) {
+                *reinterpret_cast<bf16*>(thr + P * 64) = (bf16)eacc[win_reg(P & 3)];
+                eacc[win_reg(P & 3)] = 0.f;
+                if constexpr (P == PH - 1) {
+                    *reinterpret_cast<bf16*>(thr + (P + 1) * 64) = (bf16)eacc[win_reg((P + 1) & 3)];
+                    eacc[win_reg((P + 1) & 3)] = 0.f;
+                }
+            }
+        }
+        if (j + 1 < ntile) {
+            ks.store(smem + ((j + 1) & 1) * STAGE_QK, tid);
+            vs.store(smem + ((j + 1) & 1) * STAGE_QK + IMG, tid);
+        }
+        __syncthreads();
+    };
+    for (int a = 0; a < Hp / RPP; ++a) {
+        body(std::integral_constant<int, 0>{}, a);
+        body(std::integral_constant<int, 1>{}, a);
+        body(std::integral_constant<int, 2>{}, a);
+        body(std::integral_constant<int, 3>{}, a);
+        body(std::integral_constant<int, 4>{}, a);
+        body(std::integral_constant<int, 5>{}, a);
+        body(std::integral_constant<int, 6>{}, a);
+    }
+    // every wave is past its last read of the K/V stages and the one-hot images (the loop ends with a barrier): the image region
+    // becomes the fp32 kw-gradient table [wave][32 q][28], the K/V region the per-wave dQ staging tiles
+    float* twg = reinterpret_cast<float*>(eimg + wave * (32 * WP * 4));
+    unsigned char* stg = smem + wave * IMG;
+    if (valid) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int rho = acc_row(reg, lane);
+            if (rho < 22) twg[ql * WP + rho] = eacc[reg];
+            else if (rho >= 24 && rho < 30) twg[ql * WP + rho - 2] = eacc[reg];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dq[0][r] *= scale; dq[1][r] *= scale; }
+        // r-space: dG[q][r] gathers the tables; dQ^T[d][q] += sum_r Rcat[r][d] dG[q][r]; dG is also the operand of d rel_pos.
+        // (the table gradients are plain sums of dS over the keys of a kw / kh class = d loss / d G: the bias enters the logit with
+        // coefficient 1, the 1 / scale inside T and the scale inside `sl` cancel)
+        bf16* dgrow = dG + ((size_t)(b * L + q) * H + h) * NRP;
+        for (int s = 0; s < NRP / 16; ++s) {
+            float gv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int r = 16 * s + 8 * g + t;
+                float v = 0.f;
+                if (r < 2 * Hp - 1) {
+                    const int khh = qh + Hp - 1 - r;
+                    if (khh >= 0 && khh < Hp) v = (float)*reinterpret_cast<const bf16*>(thT + khh * 64 + ql * 2);
+                } else {
+                    const int rr = r - (2 * Hp - 1);
+                    const int kww = qw + WP - 1 - rr;
+                    if (rr < 2 * WP - 1 && kww >= 0 && kww < WP) v = twg[ql * WP + kww];
+                }
+                gv[t] = v;
+            }
+            const bf16x8 gf = packfrag(gv);
+            *reinterpret_cast<uint4*>(dgrow + 16 * s + 8 * g) = __builtin_bit_cast(uint4, gf);
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+                dq[db] = mfma(gfrag(rcatT + (size_t)(db * 32 + ql) * NRP, s, g), gf, dq[db]);
+        }
+        stage_rows(stg, dq, 1.f, lane);
+        write_rows(stg, dqkv + (size_t)(b * L + qt * 32) * ldq + h * ATT_HD, ldq, lane);
+    }
+}
+
+// =============================================================================================== backward: dK, dV
+// stage = [Q img | dO img | kw part of the T tile, chunk-swizzled [32 q][64 B] | 8 kh-table rows x [32 q] bf16 (6 key rows from the
+// workgroup's first one, then -lse/scale hi, lo) | -Delta f32 [32]]
+constexpr int DKV_TW = 2 * IMG, DKV_TH = DKV_TW + 2048, DKV_ND = DKV_TH + 512, DKV_STAGE = DKV_ND + 128;
+template <int MINW>
+__global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ dout,
+                                                           size_t lddo, const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv,
+                                                           int L, int H, int Hp, float scale, int nblk, int xcd_map) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, ql = lane & 31;
+    int blk, bh;
+    wg_coords(nblk, xcd_map, blk, bh);
+    const int b = bh / H, h = bh % H, D = H * ATT_HD;
+    const bf16* qbase = qkv + (size_t)b * L * ldq + h * ATT_HD;
+    const bf16* dobase = dout + (size_t)b * L * lddo + h * ATT_HD;
+    const int kt = blk * NW + wave;
+    const bool valid = kt * 32 < L;
+    const int key = kt * 32 + ql;
+    const int kh = key / WP, kw = key % WP;
+    const int khlo = (blk * NW * 32) / WP;            // first key row of the workgroup
+    const int kha = (kt * 32) / WP;                   // the wave's 32 keys lie in key rows kha and kha + 1
+    const int ntile = L / 32;
+    const int TB = ttile_bytes(Hp);
+    const unsigned char* tbase = tables + (size_t)bh * ntile * TB;
+    LaneAddr la;
+    la.init(lane);
+    EAddr ea;                                        // the kw part of the T tile uses the layout of the one-hot images
+    ea.init(lane);
+    const float sl = scale * LOG2E_F;
+    const int sa = kha & 3, sb = (kha + 1) & 3;      // window slots of the wave's two key rows; the other two carry lse hi / lo
+
+    // B operands that never change: K, V rows and the one-hot row of this lane's key
+    bf16x8 kf[4], vf[4], eb0, eb1;
+    int woff[2];
+    {
+        uint32_t e0[4] = {0, 0, 0, 0}, e1[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const uint32_t bit = 0x3F80u << (16 * (t & 1));
+            if (kw == 8 * g + t) e0[t >> 1] |= bit;
+            if (t < 6) {
+                if (kw == 16 + 6 * g + t) e1[t >> 1] |= bit;
+            } else {
+                const int slot = 2 * g + (t - 6);
+                if (slot == (kh & 3) || (slot != sa && slot != sb)) e1[t >> 1] |= bit;
+            }
+        }
+        eb0 = __builtin_bit_cast(bf16x8, make_uint4(e0[0], e0[1], e0[2], e0[3]));
+        eb1 = __builtin_bit_cast(bf16x8, make_uint4(e1[0], e1[1], e1[2], e1[3]));
+        // A-operand side (lane = query of the streamed tile): which staged kh-table row feeds this half-wave's two window slots
+#pragma unroll
+        for (int hs = 0; hs < 2; ++hs) {
+            const int slot = 2 * g + hs;
+            int row;
+            if (slot == sa) row = kha - khlo;
+            else if (slot == sb) row = kha + 1 - khlo;
+            else {
+                int rank = 0;
+                for (int s2 = 0; s2 < slot; ++s2) rank += (s2 != sa && s2 != sb) ? 1 : 0;
+                row = 6 + rank;
+            }
+            woff[hs] = DKV_TH + row * 64 + ql * 2;
+        }
+    }
+    if (valid) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = gfrag(qbase + D + (size_t)key * ldq, s, g);
+            vf[s] = gfrag(qbase + 2 * D + (size_t)key * ldq, s, g);
+        }
+    }
+    // staging: Q tile, dO tile, and one more 16-byte chunk for the first 168 threads (kw part 128, table rows 32, -Delta 8)
+    Stager qs, dos;
+    uint4 rx = zero4();
+    int xsrc = 0, xdst = 0;
+    if (tid < 128) {
+        const int qi = tid >> 2, c = tid & 3;
+        xsrc = tid * 16;
+        xdst = DKV_TW + qi * 64 + ((c ^ ((qi >> 2) & 3)) << 4);
+    } else if (tid < 160) {
+        const int k = tid - 128, rs = k >> 2, c = k & 3;
+        const int srow = rs < 6 ? min(khlo + rs, Hp - 1) : Hp + (rs - 6);
+        xsrc = 2048 + srow * 64 + c * 16;
+        xdst = DKV_TH + rs * 64 + c * 16;
+    } else if (tid < 168) {
+        xsrc = 2048 + (Hp + 2) * 64 + (tid - 160) * 16;
+        xdst = DKV_ND + (tid - 160) * 16;
+    }
+    auto load_all = [&](int j) {
+        qs.load(qbase + (size_t)j * 32 * ldq, ldq, tid);
+        dos.load(dobase + (size_t)j * 32 * lddo, lddo, tid);
+        if (tid < 168) rx = *reinterpret_cast<const uint4*>(tbase + (size_t)j * TB + xsrc);
+    };
+    auto store_all = [&](int stage) {
+        unsigned char* s0 = smem + stage * DKV_STAGE;
+        qs.store(s0, tid);
+        dos.store(s0 + IMG, tid);
+        if (tid < 168) *reinterpret_cast<uint4*>(s0 + xdst) = rx;
+    };
+    load_all(0);
+    store_all(0);
+    __syncthreads();
+
+    f32x16 dk[2], dv[2];
+    dk[0] = zero16(); dk[1] = zero16(); dv[0] = zero16(); dv[1] = zero16();
+
+    for (int j = 0; j < ntile; ++j) {
+        if (j + 1 < ntile) load_all(j + 1);
+        const unsigned char* qimg = smem + (j & 1) * DKV_STAGE;
+        const unsigned char* doimg = qimg + IMG;
+        if (valid) {
+            const uint4 a0 = *reinterpret_cast<const uint4*>(qimg + DKV_TW + ea.row[0]);
+            uint4 a1 = *reinterpret_cast<const uint4*>(qimg + DKV_TW + ea.row[1]);
+            const uint32_t wlo = *reinterpret_cast<const uint16_t*>(qimg + woff[0]);
+            const uint32_t whi = *reinterpret_cast<const uint16_t*>(qimg + woff[1]);
+            f32x16 dpacc;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 nd = *reinterpret_cast<const float4*>(qimg + DKV_ND + (8 * rg + 4 * g) * 4);
+                dpacc[rg * 4 + 0] = nd.x; dpacc[rg * 4 + 1] = nd.y; dpacc[rg * 4 + 2] = nd.z; dpacc[rg * 4 + 3] = nd.w;
+            }
+            bf16x8 qfr[4], dofr[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { qfr[s] = rowfrag(qimg, la, s); dofr[s] = rowfrag(doimg, la, s); }
+            __builtin_amdgcn_sched_barrier(0);
+            a1.w = wlo | (whi << 16);
+            f32x16 sacc = zero16();
+            sacc = mfma(as_frag(a0), eb0, sacc);                          // S[q][key] - lse: lane = key, registers = q rows
+            sacc = mfma(as_frag(a1), eb1, sacc);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                sacc = mfma(qfr[s], kf[s], sacc);
+                dpacc = mfma(dofr[s], vf[s], dpacc);                      // dP[q][key] - Delta[q]
+            }
+            bf16x8 dotr[2][2], qtr[2][2];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                dotr[db][0] = trfrag(doimg, la, db, 0); dotr[db][1] = trfrag(doimg, la, db, 1);
+                qtr[db][0] = trfrag(qimg, la, db, 0); qtr[db][1] = trfrag(qimg, la, db, 1);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            float p[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = __builtin_amdgcn_exp2f(sacc[r] * sl);
+                ds[r] = p[r] * dpacc[r];
+            }
+            const bf16x8 pf0 = packfrag(p), pf1 = packfrag(p + 8), dsf0 = packfrag(ds), dsf1 = packfrag(ds + 8);
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                dv[db] = mfma(dotr[db][0], pf0, dv[db]);    // dV^T[d][key] += dO^T[d][q] P[q][key]
+                dv[db] = mfma(dotr[db][1], pf1, dv[db]);
+                dk[db] = mfma(qtr[db][0], dsf0, dk[db]);    // dK^T[d][key] += Q^T[d][q] dS[q][key]
+                dk[db] = mfma(qtr[db][1], dsf1, dk[db]);
+            }
+        }
+        if (j + 1 < ntile) store_all((j + 1) & 1);
+        __syncthreads();
+    }
+    unsigned char* stg = smem + wave * 2 * IMG;
+    if (valid) {
+        stage_rows(stg, dk, scale, lane);
+        stage_rows(stg + IMG, dv, 1.f, lane);
+        bf16* orow = dqkv + (size_t)(b * L + kt * 32) * ldq + h * ATT_HD;
+        write_rows(stg, orow + D, ldq, lane);
+        write_rows(stg + IMG, orow + 2 * D, ldq, lane);
+    }
+}
+
+// -lse / scale as a bf16 hi + lo pair and -Delta into the table tiles (one thread per (sample, head, query))
+__global__ void prep_kernel(const float* __restrict__ lse, const float* __restrict__ delta, unsigned char* __restrict__ tables, int L, int Hp,
+                            float inv_scale, int total) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int bh = idx / L, q = idx - bh * L, qt = q >> 5, qi = q & 31;
+    unsigned char* tt = tables + ((size_t)bh * (L / 32) + qt) * ttile_bytes(Hp);
+    const float x = -lse[idx] * inv_scale;
+    const bf16 hi = (bf16)x;
+    const bf16 lo = (bf16)(x - (float)hi);
+    *reinterpret_cast<bf16*>(tt + 2048 + Hp * 64 + qi * 2) = hi;
+    *reinterpret_cast<bf16*>(tt + 2048 + (Hp + 1) * 64 + qi * 2) = lo;
+    *reinterpret_cast<float*>(tt + 2048 + (Hp + 2) * 64 + qi * 4) = -delta[idx];
+}
+
+}   // namespace a3
+
+// PA_ATTN3=0 / pa_attn_set_generation(2): keep the generation-2 kernels for every grid (A/B runs, cross-generation tests)
+static int g_attn_generation = 0;
+extern "C" int pa_attn_set_generation(int generation) {
+    if (generation != 0 && generation != 2 && generation != 3) return (int)hipErrorInvalidValue;
+    g_attn_generation = generation;
+    return 0;
+}
+bool attn3_ok(int L, int Hp, int Wp) {
+    static const int on = [] { const char* e = getenv("PA_ATTN3"); return e ? atoi(e) : 1; }();
+    return on && g_attn_generation != 2 && Wp == a3::WP && Hp % a3::RPP == 0 && Hp >= a3::RPP && L == Hp * Wp;
+}
+int64_t attn3_table_bytes(int Bn, int L, int H, int Hp, int Wp) {
+    if (!attn3_ok(L, Hp, Wp)) return 0;
+    return (int64_t)Bn * H * (L / 32) * a3::ttile_bytes(Hp);
+}
+static int a3_xcd_map_on() {
+    static const int v = [] { const char* e = getenv("PA_ATTN_XCD"); return e ? atoi(e) : 1; }();
+    return v;
+}
+
+int attn3_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t ldo, float* lse, void* tables, int Bn, int L, int H,
+              int Hp, int Wp, float scale, hipStream_t st) {
+    using namespace a3;
+    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    // PA_ATTN3_FWD_STAGES: 1 (default) = single K/V stage, 4 workgroups per CU; 2 = double-buffered, one barrier per tile
+    static const int stages = [] { const char* v = getenv("PA_ATTN3_FWD_STAGES"); return v ? atoi(v) : 1; }();
+    const size_t smem = (size_t)(stages == 2 ? 2 : 1) * STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG;
+    static bool done1 = false, done2 = false;
+    auto kern = stages == 2 ? fwd_kernel<2> : fwd_kernel<1>;
+    if (int e = set_smem(reinterpret_cast<const void*>(kern), stages == 2 ? done2 : done1)) return e;
+    const int nblk = (L / 32 + NW - 1) / NW;
+    PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, out, (size_t)ldo, lse,
+              reinterpret_cast<unsigned char*>(tables), L, H, Hp, NRP, scale, nblk, a3_xcd_map_on());
+    return (int)hipGetLastError();
+}
+
+int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const float* delta,
+              void* tables, bf16* dqkv, bf16* dG, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st) {
+    using namespace a3;
+    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    const int nblk = (L / 32 + NW - 1) / NW;
+    unsigned char* tb = reinterpret_cast<unsigned char*>(tables);
+    int e;
+    {
+        const int total = Bn * H * L;
+        PA_LAUNCH(prep_kernel, dim3((total + 255) / 256), dim3(256), 0, st, lse, delta, tb, L, Hp, 1.f / scale, total);
+        if ((e = (int)hipGetLastError())) return e;
+    }
+    // PA_ATTN3_DQ_WAVES / PA_ATTN3_DKV_WAVES: waves per SIMD the register allocation aims at (2 or 3)
+    static const int dq_w = [] { const char* v = getenv("PA_ATTN3_DQ_WAVES"); return v ? atoi(v) : 2; }();
+    static const int dkv_w = [] { const char* v = getenv("PA_ATTN3_DKV_WAVES"); return v ? atoi(v) : 2; }();
+    {
+        const size_t smem = 2 * (size_t)STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG;
+        auto kern = dq_w == 3 ? bwd_dq_kernel<3, false> : bwd_dq_kernel<2, true>;
+        static bool done2 = false, done3 = false;
+        if ((e = set_smem(reinterpret_cast<const void*>(kern), dq_w == 3 ? done3 : done2))) return e;
+        PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcatT, dout, (size_t)lddo, lse, tb, dqkv, dG, L, H, Hp,
+                  NRP, scale, nblk, a3_xcd_map_on());
+        if ((e = (int)hipGetLastError())) return e;
+    }
+    {
+        size_t smem = 2 * (size_t)DKV_STAGE;
+        if (smem < (size_t)NW * 2 * IMG) smem = (size_t)NW * 2 * IMG;
+        auto kern = dkv_w == 3 ? bwd_dkv_kernel<3> : bwd_dkv_kernel<2>;
+        static bool done2 = false, done3 = false;
+        if ((e = set_smem(reinterpret_cast<const void*>(kern), dkv_w == 3 ? done3 : done2))) return e;
+        PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, dout, (size_t)lddo, tb, dqkv, L, H, Hp, scale, nblk,
+                  a3_xcd_map_on());
+        return (int)hipGetLastError();
+    }
+}

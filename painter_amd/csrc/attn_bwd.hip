@@ -15,6 +15,7 @@
 #include "gemm_engine.h"
 #include "../../include/painter_hip.h"
 #include "attn2.h"
+#include "attn3.h"
 
 // ------------------------------------------------------------------------------- Delta pre-pass
 template <typename T> __global__ void attn_delta_kernel(const T* o, size_t ldo, const T* d_o, size_t lddo, float* delta, int R, int L, int H) {
@@ -472,9 +473,12 @@ static int attn_bwd_t(const T* qkv, int64_t ldq, const T* rcat, const T* rcatT, 
 
 // dqkv: T [batch*L, 3*heads*64] (same layout as qkv); dG: T [batch*L, heads*NRP]; aux: pa_attn_bwd_aux_bytes scratch
 extern "C" int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, const void* rcatT, const void* dout, int64_t lddo,
-                           const float* lse, const float* delta, void* dqkv, void* dG, void* aux, int batch, int L, int heads, int Hp,
-                           int Wp, float scale, hipStream_t st) {
+                           const float* lse, const float* delta, void* dqkv, void* dG, void* aux, void* tables, int batch, int L,
+                           int heads, int Hp, int Wp, float scale, hipStream_t st) {
     if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4) return (int)hipErrorInvalidValue;
+    if (dtype == PA_BF16 && tables != nullptr && attn3_ok(L, Hp, Wp))
+        return attn3_bwd((const bf16*)qkv, ldq, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, tables, (bf16*)dqkv, (bf16*)dG,
+                         batch, L, heads, Hp, Wp, scale, st);
     if (dtype == PA_BF16 && attn2_ok(L, Hp, Wp))
         return attn2_bwd((const bf16*)qkv, ldq, (const bf16*)rcat, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, (bf16*)dqkv,
                          (bf16*)dG, aux, batch, L, heads, Hp, Wp, scale, st);

@@ -12,6 +12,7 @@
 #include "attn_common.h"
 #include "../../include/painter_hip.h"
 #include "attn2.h"
+#include "attn3.h"
 
 template <typename T, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__ qkv, size_t ldq, const T* __restrict__ rcat,
@@ -206,10 +207,15 @@ static int attn_fwd_launch(const T* qkv, int64_t ldq, const T* rcat, T* out, int
 }
 
 // qkv: [B', L, 3, H, 64] T (row stride ldq = 3*H*64); rcat from pa_relpos_pack; out: [B'*L, H*64] T; lse: [B'*H, L] fp32
-extern "C" int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse,
+extern "C" int64_t pa_attn_tables_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp) {
+    return dtype == PA_BF16 ? attn3_table_bytes(batch, L, heads, Hp, Wp) : 0;
+}
+extern "C" int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse, void* tables,
                            int batch, int L, int heads, int Hp, int Wp, float scale, hipStream_t st) {
     if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4 || 32 % 4) return (int)hipErrorInvalidValue;
     const bool seven = ((L / 32) % 7 == 0);
+    if (dtype == PA_BF16 && attn3_ok(L, Hp, Wp))
+        return attn3_fwd((const bf16*)qkv, ldq, (const bf16*)rcat, (bf16*)out, ldo, lse, tables, batch, L, heads, Hp, Wp, scale, st);
     if (dtype == PA_BF16 && attn2_ok(L, Hp, Wp))
         return attn2_fwd((const bf16*)qkv, ldq, (const bf16*)rcat, (bf16*)out, ldo, lse, batch, L, heads, Hp, Wp, scale, st);
     if (dtype == PA_BF16) {

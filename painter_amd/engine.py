@@ -161,7 +161,8 @@ class HotPath:
             ln1, mean1, rstd1 = ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], c.ln_eps, T)
             qkv = ops.linear_fwd(ln1, self.w(pre + "attn.qkv.weight", P), P[pre + "attn.qkv.bias"], EPI_BIAS)
             rcat = ops.relpos_pack(P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], c.Hp, c.Wp, T)
-            ao, lse = ops.attn_fwd(qkv, rcat, Bc, L, c.heads, c.Hp, c.Wp, c.scale)
+            ao, lse, atab = ops.attn_fwd(qkv, rcat, Bc, L, c.heads, c.Hp, c.Wp, c.scale, need_tables=True) if need_grad else \
+                ops.attn_fwd(qkv, rcat, Bc, L, c.heads, c.Hp, c.Wp, c.scale) + (None,)
             if merge > 0:
                 if need_grad:
                     raise NotImplementedError("SegGPT feature ensemble is inference-only (as in the reference: @torch.no_grad, seggpt_engine.py:26)")
@@ -176,7 +177,7 @@ class HotPath:
             x2 = ops.linear_fwd(act, self.w(pre + "mlp.fc2.weight", P), P[pre + "mlp.fc2.bias"], EPI_BIAS_RESID,
                                 resid=x1, rowscale=ds_m, rows_per_sample=L)
             if need_grad:
-                S.blocks.append((x, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc))
+                S.blocks.append((x, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc, atab))
             x = x2
             if i == c.merge_idx:
                 Bc = B
@@ -293,7 +294,7 @@ class HotPath:
         dyT_next = None
         for i in reversed(range(c.depth)):
             pre = "blocks.%d." % i
-            x0, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc = S.blocks[i]
+            x0, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc, atab = S.blocks[i]
             S.blocks[i] = None
             R = Bc * L
             ds_a, ds_m = (None, None) if S.drop is None else S.drop[i]
@@ -332,7 +333,7 @@ class HotPath:
             tr("%d.dao" % i, dao)
             del dyA
             rcatT = ops.relpos_pack_t(P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], c.Hp, c.Wp, T)
-            dqkv, dG = ops.attn_bwd_core(qkv, rcat, rcatT, ao, dao, lse, Bc, L, c.heads, c.Hp, c.Wp, c.scale)
+            dqkv, dG = ops.attn_bwd_core(qkv, rcat, rcatT, ao, dao, lse, Bc, L, c.heads, c.Hp, c.Wp, c.scale, tables=atab)
             drcat = on_side(lambda: ops.attn_bwd_relpos(dG, qkv, rcat.shape[0], Bc, L, c.heads, c.Hp, c.Wp), dG, qkv)
             del dG
             tr("%d.dqkv" % i, dqkv)
@@ -351,7 +352,7 @@ class HotPath:
                                        rowscale=ds_next if dyT_next is not None else None, rows_per_sample=L)
             G[pre + "norm1.weight"], G[pre + "norm1.bias"] = gb[0], gb[1]
             tr("%d.dx_ln1" % i, dx)
-            del x0, ln1, qkv, ao, x1, ln2, hpre, act
+            del x0, ln1, qkv, ao, x1, ln2, hpre, act, atab
             ready([n for n in G if n.startswith(pre)])
         G["norm.weight"], G["norm.bias"] = dnorm[0], dnorm[1]
         # ---- token assembly + patch embed

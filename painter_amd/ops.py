@@ -147,14 +147,20 @@ def relpos_pack(rel_pos_h, rel_pos_w, Hp, Wp, dtype):
     return rcat
 
 
-def attn_fwd(qkv, rcat, batch, L, heads, Hp, Wp, scale):
-    """qkv [batch*L, 3*heads*64] T -> (out [batch*L, heads*64] T, lse [batch*heads, L] f32)."""
+def attn_fwd(qkv, rcat, batch, L, heads, Hp, Wp, scale, need_tables=False):
+    """qkv [batch*L, 3*heads*64] T -> (out [batch*L, heads*64] T, lse [batch*heads, L] f32[, tables]).
+    need_tables: also return the per-query bias tables the backward reuses (None when the kernels in use do not export them)."""
     T = qkv.dtype
     out = torch.empty((batch * L, heads * 64), dtype=T, device=qkv.device)
     lse = torch.empty((batch * heads, L), dtype=torch.float32, device=qkv.device)
-    check(lib.pa_attn_fwd(code(T), p(qkv), qkv.stride(0), p(rcat), p(out), out.stride(0), p(lse), batch, L, heads, Hp, Wp,
-                          float(scale), stream()), "pa_attn_fwd")
-    return out, lse
+    tables = None
+    if need_tables:
+        nb = lib.pa_attn_tables_bytes(code(T), batch, L, heads, Hp, Wp)
+        if nb > 0:
+            tables = torch.empty((nb,), dtype=torch.uint8, device=qkv.device)
+    check(lib.pa_attn_fwd(code(T), p(qkv), qkv.stride(0), p(rcat), p(out), out.stride(0), p(lse), p(tables), batch, L, heads,
+                          Hp, Wp, float(scale), stream()), "pa_attn_fwd")
+    return (out, lse, tables) if need_tables else (out, lse)
 
 
 def relpos_pack_t(rel_pos_h, rel_pos_w, Hp, Wp, dtype):
@@ -164,8 +170,9 @@ def relpos_pack_t(rel_pos_h, rel_pos_w, Hp, Wp, dtype):
     return rcatT
 
 
-def attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale):
-    """-> (dqkv T [batch*L, 3*heads*64], dG T [batch*L, heads*NRP]): the data gradients and the per-query bias gradients."""
+def attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale, tables=None):
+    """-> (dqkv T [batch*L, 3*heads*64], dG T [batch*L, heads*NRP]): the data gradients and the per-query bias gradients.
+    tables: what attn_fwd(need_tables=True) returned (the backward writes its lse / delta fields into it)."""
     T = qkv.dtype
     dev = qkv.device
     nrp = rcat.shape[0]
@@ -176,7 +183,7 @@ def attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, sca
     dG = torch.empty((batch * L, heads * nrp), dtype=T, device=dev)
     aux = workspace(lib.pa_attn_bwd_aux_bytes(batch, L, heads, Hp, Wp), dev, slot=1)
     check(lib.pa_attn_bwd(code(T), p(qkv), qkv.stride(0), p(rcat), p(rcatT), p(dout), dout.stride(0), p(lse), p(delta),
-                          p(dqkv), p(dG), p(aux), batch, L, heads, Hp, Wp, float(scale), stream()), "pa_attn_bwd")
+                          p(dqkv), p(dG), p(aux), p(tables), batch, L, heads, Hp, Wp, float(scale), stream()), "pa_attn_bwd")
     return dqkv, dG
 
 
@@ -190,9 +197,9 @@ def attn_bwd_relpos(dG, qkv, nrp, batch, L, heads, Hp, Wp):
     return drcat
 
 
-def attn_bwd(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale):
+def attn_bwd(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale, tables=None):
     """-> (dqkv T [batch*L, 3*heads*64], drcat f32 [NRP, 64])."""
-    dqkv, dG = attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale)
+    dqkv, dG = attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale, tables=tables)
     return dqkv, attn_bwd_relpos(dG, qkv, rcat.shape[0], batch, L, heads, Hp, Wp)
 
 

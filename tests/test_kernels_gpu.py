@@ -170,10 +170,25 @@ def attn_reference(qkv, rel_h, rel_w, B, L, H, Hp, Wp, scale):
     return o.view(B, H, L, 64).permute(0, 2, 1, 3).reshape(B * L, D), lse
 
 
+@pytest.fixture
+def attn_generation():
+    """pa_attn_set_generation for the duration of one test (0 = newest kernels that cover the grid, 2 = never generation 3)."""
+    from painter_amd._lib import lib
+
+    def set_(g):
+        assert lib.pa_attn_set_generation(g) == 0
+    yield set_
+    lib.pa_attn_set_generation(0)
+
+
+@pytest.mark.parametrize("gen_", [0, 2])
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,Hp,Wp", [(1, 2, 8, 4), (2, 2, 56, 28), (1, 1, 16, 8), (1, 2, 8, 12), (2, 1, 8, 20), (1, 2, 16, 16),
-                                        (1, 1, 8, 24), (1, 3, 16, 28)])
-def test_attn_fwd(T, B, H, Hp, Wp):
+                                        (1, 1, 8, 24), (1, 3, 16, 28), (1, 1, 8, 28)])
+def test_attn_fwd(T, B, H, Hp, Wp, gen_, attn_generation):
+    if gen_ == 2 and not (T == torch.bfloat16 and Wp == 28):
+        pytest.skip("generation switch only matters where generation 3 applies")
+    attn_generation(gen_)
     L = Hp * Wp
     qkv = gen((B * L, 3 * H * 64), 1, 1.0, T)
     rel_h = gen((2 * Hp - 1, 64), 2, 0.2)
@@ -187,10 +202,14 @@ def test_attn_fwd(T, B, H, Hp, Wp):
     assert e_o < (2e-5 if T == torch.float32 else 2e-2), (e_o, e_l)
 
 
+@pytest.mark.parametrize("gen_", [0, 2])
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,Hp,Wp", [(1, 2, 8, 4), (2, 2, 56, 28), (3, 1, 16, 8), (1, 2, 8, 12), (2, 1, 8, 20), (1, 2, 16, 16),
-                                        (1, 1, 8, 24), (1, 3, 16, 28)])
-def test_attn_bwd(T, B, H, Hp, Wp):
+                                        (1, 1, 8, 24), (1, 3, 16, 28), (1, 1, 8, 28)])
+def test_attn_bwd(T, B, H, Hp, Wp, gen_, attn_generation):
+    if gen_ == 2 and not (T == torch.bfloat16 and Wp == 28):
+        pytest.skip("generation switch only matters where generation 3 applies")
+    attn_generation(gen_)
     L = Hp * Wp
     nh, nw = 2 * Hp - 1, 2 * Wp - 1
     qkv = gen((B * L, 3 * H * 64), 1, 1.0, T)
@@ -200,8 +219,9 @@ def test_attn_bwd(T, B, H, Hp, Wp):
     rcat = ops.relpos_pack(rel_h, rel_w, Hp, Wp, T)
     rcatT = ops.relpos_pack_t(rel_h, rel_w, Hp, Wp, T)
     assert torch.equal(rcatT.t().contiguous(), rcat)
-    out, lse = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125)
-    dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125)
+    out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
+    assert (tables is not None) == (gen_ == 0 and T == torch.bfloat16 and Wp == 28 and Hp % 8 == 0)
+    dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables)
     q64 = qkv.double().clone().requires_grad_(True)
     rh64 = rcat[:nh].double().clone().requires_grad_(True)
     rw64 = rcat[nh:nh + nw].double().clone().requires_grad_(True)
@@ -245,6 +265,66 @@ def test_attn2_bf16_spiked_key_rebase():
     out, lse = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125)
     ref, lse_ref = attn_reference(qkv, rcat[: 2 * Hp - 1], rcat[2 * Hp - 1: 2 * Hp + 2 * Wp - 2], B, L, H, Hp, Wp, 0.125)
     assert relerr(out.float(), ref) < 2e-2 and relerr(lse, lse_ref) < 2e-3
+
+
+def _attn3_inputs(B, H, Hp, Wp, spike=False):
+    L = Hp * Wp
+    qkv = gen((B * L, 3 * H * 64), 11, 1.0)
+    if spike:                          # key L-5 answers query 7 with a logit far above everything seen before (last key tile)
+        qkv[7, 0:64] = 3.0
+        qkv[L - 5, H * 64: H * 64 + 64] = 3.0
+        qkv[40, 0:64] = -2.0
+        qkv[3 * 28 + 9, H * 64: H * 64 + 64] = -2.0
+    qkv = qkv.to(torch.bfloat16)
+    rel_h, rel_w = gen((2 * Hp - 1, 64), 2, 0.2), gen((2 * Wp - 1, 64), 3, 0.2)
+    rcat = ops.relpos_pack(rel_h, rel_w, Hp, Wp, torch.bfloat16)
+    rcatT = ops.relpos_pack_t(rel_h, rel_w, Hp, Wp, torch.bfloat16)
+    dout = gen((B * L, H * 64), 4, 1.0, torch.bfloat16)
+    return L, qkv, rcat, rcatT, dout
+
+
+def test_attn3_bf16_spiked_key_rebase():
+    """generation-3 forward + backward with a late, large logit (forces the running-max re-base) vs the fp64 reference."""
+    B, H, Hp, Wp = 1, 1, 8, 28
+    L, qkv, rcat, rcatT, dout = _attn3_inputs(B, H, Hp, Wp, spike=True)
+    out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
+    assert tables is not None
+    ref, lse_ref = attn_reference(qkv, rcat[: 2 * Hp - 1], rcat[2 * Hp - 1: 2 * Hp + 2 * Wp - 2], B, L, H, Hp, Wp, 0.125)
+    assert relerr(out.float(), ref) < 2e-2 and relerr(lse, lse_ref) < 2e-3
+    dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables)
+    q64 = qkv.double().clone().requires_grad_(True)
+    o64, _ = attn_reference(q64, rcat[: 2 * Hp - 1].double(), rcat[2 * Hp - 1: 2 * Hp + 2 * Wp - 2].double(), B, L, H, Hp, Wp, 0.125)
+    o64.backward(dout.double())
+    assert relerr(dqkv.float(), q64.grad) < 3e-2
+
+
+def test_attn_generations_agree(attn_generation):
+    """The two bf16 generations on identical inputs (ViT-L grid, B' = 2): they share no bias code path (k-space tables + VALU adds
+    vs one-hot contraction on the matrix pipe), so a dropped or mis-indexed rel-pos term in either shows up here at full size.
+    The bound is a few bf16 roundings of the bias tables (generation 3 rounds the kw table to bf16, generation 2 keeps it fp32)."""
+    B, H, Hp, Wp = 2, 2, 56, 28
+    L, qkv, rcat, rcatT, dout = _attn3_inputs(B, H, Hp, Wp)
+    res = {}
+    for g_ in (2, 0):
+        attn_generation(g_)
+        out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
+        dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables)
+        res[g_] = (out.float(), lse, dqkv.float(), drcat)
+    assert relerr(res[0][1], res[2][1]) < 1e-3
+    for a, b in zip(res[0], res[2]):
+        assert relerr(a, b) < 1.5e-2, [relerr(x, y) for x, y in zip(res[0], res[2])]
+
+
+def test_attn3_deterministic():
+    B, H, Hp, Wp = 1, 2, 16, 28
+    L, qkv, rcat, rcatT, dout = _attn3_inputs(B, H, Hp, Wp)
+    runs = []
+    for _ in range(2):
+        out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
+        dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables)
+        runs.append((out.clone(), lse.clone(), dqkv.clone(), drcat.clone()))
+    for a, b in zip(*runs):
+        assert torch.equal(a, b)
 
 
 def test_determinism_same_input_bit_identical():
