@@ -1,25 +1,34 @@
 #!/usr/bin/env python
 """Headline benchmark (BASELINE.json): images/sec of the Painter ViT-L forward+backward on 896x448 stitched pairs.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the hot path over one batch: forward + backward of
-painter_vit_large_patch16_input896x448 (train mode: DropPath active), per-GPU batch 8, bf16 operands / fp32 accumulate,
-synthetic inputs already resident in HBM; for N > 1 the gradient all-reduce (RCCL, bucketed, overlapped with backward)
-is inside the step.  Prints ONE JSON line on rank 0 (contract in the task statement):
-  value       = N * B * K / t      images/sec, t = max over ranks of the barrier-bracketed wall time of exactly K steps
-  roofline    = the dominant kernel family's largest forward instantiation (256x256 bf16 MFMA GEMM, Mlp.fc1 + GELU) measured
-                live with HIP events on the launch stream over the timed region: achieved TFLOP/s = algorithmic
-                FLOPs (2.M.N.K per launch) of those launches / their summed duration; peak = 2500 TFLOP/s dense bf16 MFMA;
-                `traffic` = HBM bytes per launch from the PMC pass (profiles/roofline_traffic.json).  `other_kernels`
-                carries the same measurement for the attention forward and the (side-stream, overlapped) weight gradient.
-                `model_mfma_frac` = images/s/GPU * 4.034 TFLOP (attention+MLP fwd+bwd) / 2.5 PFLOP/s.
-  cpu_baseline = the CPU oracle (oracle/painter_oracle.py, kind "port"; /root/reference does not exist on the GPU box)
-                timed on the host cores: ONE forward+backward at B=1, 896x448, fp32 (about 10-30 s).
+N > 1: one rank per GPU over RCCL.  Started without a launcher (WORLD_SIZE unset) the script re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (what the reference's
+train_painter_vit_large.sh:5-8 does); started by a launcher it checks WORLD_SIZE against --gpus and refuses a mismatch -- it never
+prints a line for fewer GPUs than asked for.
+
+A "step" = one pass of the hot path over one batch: forward + backward of painter_vit_large_patch16_input896x448 (train mode:
+DropPath active), per-GPU batch 8, bf16 operands / fp32 accumulate, synthetic inputs already resident in HBM; for N > 1 the gradient
+all-reduce (RCCL, bucketed, overlapped with backward) is inside the step.  Prints ONE JSON line on rank 0:
+  value        = N * B * K / t     images/sec, t = max over ranks of the barrier-bracketed wall time of exactly K steps.  Nothing
+                 is instrumented inside the timed region.
+  roofline     = SURVEY.md 8(d): achieved = images/s/GPU * 4.034 TFLOP (attention + MLP blocks, fwd+bwd), peak =
+                 2500 TFLOP/s dense bf16 MFMA, frac = achieved / peak (whole-model accounting, 4.769 TFLOP, beside it).
+                 `dominant_kernel` = the kernel family with the largest summed duration in a SEPARATE profiled pass after the timed
+                 region (HIP events around every launch on the launching stream; second stream off, so a duration is the kernel's
+                 own): algorithmic FLOPs of its launches / their summed duration, against the same peak; `kernels` lists every family.
+                 `traffic` = HBM bytes per launch of the dominant family's largest forward instantiation from the PMC passes
+                 (profiles/roofline_traffic.json, tools/pmc_traffic.py) or null.
+  cpu_baseline = the CPU oracle (oracle/painter_oracle.py = the reference's forward restated op for op in PyTorch-CPU, kind "port":
+                 /root/reference does not exist on the GPU box) on the host cores, all of them, B = 1, fp32: eval forward and train
+                 forward+backward, 1 warm-up + 3 timed runs each; value = fwd+bwd images/sec from the median.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -63,59 +72,108 @@ def synthetic_inputs(batch, H, W, L, seed, device):
     return imgs, tgts, mask.to(device), valid
 
 
-class KernelTimer:
-    """HIP-event brackets around every launch of a few ops inside the timed region.  Events are recorded on the stream the
-    op is launched on (torch's current stream at the call: the caller's stream, or the engine's side stream for weight
-    gradients).  -> per op: launches, summed duration, algorithmic FLOPs."""
+def _mnk(a_rows, a_cols, b_rows):
+    return 2.0 * a_rows * a_cols * b_rows
 
-    FLOPS = {
-        "fc1": lambda a, k: 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[0],                    # linear_gelu(x, w, bias)
-        "attn_fwd": lambda a, k: 4.0 * a[2] * a[4] * a[3] * a[3] * 64,                               # (qkv, rcat, batch, L, heads, ...)
-        "wgrad": lambda a, k: 2.0 * a[0].shape[0] * a[0].shape[1] * a[1].shape[1],                   # linear_wgrad(dy, x)
+
+class KernelTimer:
+    """HIP-event brackets around every launch of the MFMA-bound ops, used in a profiled pass AFTER the timed region.  Events are
+    recorded on the stream the op is launched on (torch's current stream at the call).  -> per family: launches, summed duration,
+    algorithmic FLOPs."""
+
+    # op -> (family, algorithmic FLOPs of one call)
+    OPS = {
+        "linear_fwd": ("gemm256_fwd", lambda a, k: _mnk(a[0].shape[0], a[0].shape[1], a[1].shape[0])),          # (x [M,K], w [N,K])
+        "linear_gelu": ("gemm256_fwd", lambda a, k: _mnk(a[0].shape[0], a[0].shape[1], a[1].shape[0])),
+        "linear_pixshuf": ("gemm256_fwd", lambda a, k: _mnk(a[0].shape[0], a[0].shape[1], a[1].shape[0])),
+        "linear_dgrad": ("gemm256_dgrad", lambda a, k: _mnk(a[0].shape[0], a[0].shape[1], a[1].shape[1])),      # (dy [M,N], w [N,K])
+        "linear_wgrad": ("gemm256_wgrad", lambda a, k: _mnk(a[0].shape[0], a[0].shape[1], a[1].shape[1])),      # (dy [M,N], x [M,K])
+        "attn_fwd": ("attention_fwd", lambda a, k: 4.0 * a[2] * a[4] * a[3] * a[3] * 64),                       # (qkv, rcat, batch, L, heads)
+        "attn_bwd_core": ("attention_bwd", lambda a, k: 10.0 * a[6] * a[8] * a[7] * a[7] * 64),                 # 2.5 x forward
     }
-    TARGET = {"fc1": "linear_gelu", "attn_fwd": "attn_fwd", "wgrad": "linear_wgrad"}
+    NAMES = {
+        "gemm256_fwd": "g256::gemm256_kernel<false,false,*> (nn.Linear forward: qkv, proj, fc1+GELU, fc2, decoder_embed)",
+        "gemm256_dgrad": "g256::gemm256_kernel<false,true,*> (nn.Linear data gradient dX = dY.W)",
+        "gemm256_wgrad": "g256::gemm256_kernel<true,true,Epi4Slab> + slab_reduce (weight gradient dW = dY^T.X)",
+        "attention_fwd": "a3::fwd_kernel (fused attention forward, rel-pos bias on the matrix pipe)",
+        "attention_bwd": "a3::bwd_dq_kernel + a3::bwd_dkv_kernel + delta/prep (fused attention backward, 2.5x the forward's FLOPs)",
+    }
 
     def __init__(self, ops_mod):
         self.ops, self.active = ops_mod, False
-        self.rec = {k: {"events": [], "flops": 0.0} for k in self.TARGET}
+        self.rec = {}
 
     def install(self):
-        for key, fname in self.TARGET.items():
+        for fname, (family, flops) in self.OPS.items():
             orig = getattr(self.ops, fname)
 
-            def wrapped(*a, _orig=orig, _key=key, **kw):
+            def wrapped(*a, _orig=orig, _family=family, _flops=flops, **kw):
                 if not self.active:
                     return _orig(*a, **kw)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 r = _orig(*a, **kw)
                 e1.record()
-                self.rec[_key]["events"].append((e0, e1))
-                self.rec[_key]["flops"] += self.FLOPS[_key](a, kw)
+                ent = self.rec.setdefault(_family, {"events": [], "flops": 0.0})
+                ent["events"].append((e0, e1))
+                ent["flops"] += _flops(a, kw)
                 return r
 
             setattr(self.ops, fname, wrapped)
 
-    def result(self, key):
-        ev = self.rec[key]["events"]
-        ms = sum(a.elapsed_time(b) for a, b in ev)
-        return len(ev), ms, (self.rec[key]["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
+    def results(self, peak):
+        out = {}
+        for fam, ent in self.rec.items():
+            ms = sum(a.elapsed_time(b) for a, b in ent["events"])
+            n = len(ent["events"])
+            tf = ent["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out[fam] = {"kernel": self.NAMES[fam], "launches": n, "kernel_ms_total": round(ms, 3), "avg_us": round(ms / max(n, 1) * 1e3, 2),
+                        "achieved": round(tf, 2), "frac": round(tf / peak, 4)}
+        return out
 
 
 def cpu_baseline():
-    """One fp32 forward+backward of the CPU oracle at B=1 (ViT-L, 896x448) on the host cores."""
+    """The CPU oracle at B=1 (ViT-L, 896x448, fp32) on every host core: eval forward and train forward+backward, 1 warm-up + 3 timed."""
+    import statistics
+
     from oracle import painter_oracle as O
-    torch.set_num_threads(min(os.cpu_count(), 32))     # more threads only add contention at B=1
+    ncpu = os.cpu_count()
+    torch.set_num_threads(ncpu)
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+    except Exception:
+        phys = None
     cfg = O.vit_large_config()
     P = {k: v.requires_grad_(True) for k, v in O.random_params(cfg, 1).items()}
     imgs, tgts, mask, valid = O.synthetic_batch(cfg, 1, 1234, "half")
-    t0 = time.time()
-    loss, _, _ = O.forward(P, cfg, imgs, tgts, mask, valid)
-    loss.backward()
-    dt = time.time() - t0
-    return {"value": round(1.0 / dt, 5), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle/painter_oracle.py (CPU restatement of the reference, PyTorch fp32), ViT-L 896x448, B=1, "
-                      "one forward+backward, %.1f s, no warm-up" % dt}
+
+    def fwd_eval():
+        with torch.no_grad():
+            O.forward(P, cfg, imgs, tgts, mask, valid.clone())
+
+    def fwd_bwd():
+        for v in P.values():
+            v.grad = None
+        loss, _, _ = O.forward(P, cfg, imgs, tgts, mask, valid.clone())
+        loss.backward()
+
+    def timed(fn):
+        fn()
+        ts = []
+        for _ in range(3):
+            t0 = time.time()
+            fn()
+            ts.append(time.time() - t0)
+        return statistics.median(ts), ts
+
+    te, tes = timed(fwd_eval)
+    tt, tts = timed(fwd_bwd)
+    return {"value": round(1.0 / tt, 5), "unit": "images/sec", "cores": torch.get_num_threads(), "physical_cores": phys, "kind": "port",
+            "eval_forward_images_per_sec": round(1.0 / te, 5),
+            "sample": "oracle/painter_oracle.py (the reference forward restated op for op, PyTorch-CPU fp32), ViT-L 896x448, B=1, "
+                      "torch.set_num_threads(%d); 1 warm-up + 3 timed runs each: eval forward %s s, forward+backward %s s; value = 1 / median "
+                      "forward+backward" % (ncpu, ["%.2f" % t for t in tes], ["%.2f" % t for t in tts])}
 
 
 def optimizer_step_ms(model, step_fn):
@@ -153,6 +211,26 @@ def optimizer_step_ms(model, step_fn):
     return res
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def relaunch_under_launcher(args):
+    """--gpus N > 1 without a launcher: start N ranks ourselves (one per GPU, RCCL) and hand back their exit code."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit("bench.py: --gpus %d asked for, %d visible -- refusing to print a line for fewer GPUs" % (args.gpus, n_dev))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -160,28 +238,34 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE configs[1]: 8)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--roofline-kernel", default="fc1", choices=["fc1", "attn_fwd", "wgrad"])
+    ap.add_argument("--profile-steps", type=int, default=2, help="steps of the separate, event-instrumented pass after the timed region (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--eval", action="store_true", help="eval mode (no DropPath)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(relaunch_under_launcher(args))
+
     from painter_amd import models_painter, ops, parallel
     rank, local, world = parallel.init_distributed()
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    distributed = world > 1 or parallel._SELFTEST
+    if distributed:
+        import torch.distributed as dist
+        assert dist.get_world_size() == world
 
     model = models_painter.painter_vit_large_patch16_input896x448(compute_dtype=args.dtype)
-    randomize_parameters(model, seed=1)
+    randomize_parameters(model, seed=1 + rank)              # replicas start different (main_train.py:190) ...
     model = model.to(dev)
     model.train(not args.eval)
-    if world > 1 or parallel._SELFTEST:
-        import torch.distributed as dist
-        for p in model.parameters():                      # C2: replicas start identical (same seed; broadcast anyway)
-            dist.broadcast(p.data, src=0)
+    if distributed:
+        parallel.broadcast_parameters(model)                # ... and adopt rank 0's parameters, as under the DDP wrapper
         model.grad_sync = parallel.GradSync()
     cfg = model._cfg
     imgs, tgts, mask, valid = synthetic_inputs(args.batch, cfg.H, cfg.W, cfg.L, 1234 + rank, dev)
@@ -194,79 +278,90 @@ def main():
         return loss
 
     timer = KernelTimer(ops)
-    timer.install()
+    timer.install()                                          # inert (one attribute test per op call) until .active is set
     for _ in range(args.warmup):
         step()
 
     def barrier():
-        if world > 1 or parallel._SELFTEST:
+        if distributed:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
     barrier()
-    timer.active = True
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     torch.cuda.synchronize()
     barrier()
     dt = time.perf_counter() - t0
-    timer.active = False
     lossv = float(loss.item())
-    if world > 1 or parallel._SELFTEST:
+    n_ranks = world
+    if distributed:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+        n_ranks = torch.distributed.get_world_size()
+
+    # ---- separate profiled pass (never compare a profiled arm with an un-profiled one: `value` above is un-instrumented)
+    kernels = {}
+    if args.profile_steps > 0 and not distributed:          # single rank only: the extra steps would need every rank's all-reduce
+        side = model._hot.use_side_stream
+        model._hot.use_side_stream = False                  # one stream: an event pair brackets exactly its own kernels
+        step()
+        timer.active = True
+        for _ in range(args.profile_steps):
+            step()
+        torch.cuda.synchronize()
+        timer.active = False
+        model._hot.use_side_stream = side
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        kernels = timer.results(peak)
+        for v in kernels.values():
+            v["ms_per_step"] = round(v["kernel_ms_total"] / args.profile_steps, 3)
 
     if rank == 0:
-        ips = world * args.batch * args.steps / dt
-        n, kms, tf = timer.result(args.roofline_kernel)
+        ips = n_ranks * args.batch * args.steps / dt
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
-        KNAME = {
-            "fc1": "g256::gemm256_kernel<false,false,Epi4BiasGelu> (Mlp.fc1 forward: [R,1024]x[1024,4096] + bias + erf-GELU, writes "
-                   "pre-activation and activation; the largest forward instantiation of the 256x256 bf16 MFMA GEMM that carries "
-                   "52% of the step's kernel time; forward launches do not overlap the side stream, so the event time is the "
-                   "kernel's own)",
-            "attn_fwd": "a2::fwd_kernel (fused attention forward with decomposed rel-pos bias)",
-            "wgrad": "g256::gemm256_kernel<true,true,Epi4Slab> (weight gradient dW = dY^T.X on the side stream: runs CONCURRENTLY "
-                     "with the main stream's dgrad/attention kernels, so its duration includes time-sharing)",
-        }
-        kname = KNAME[args.roofline_kernel]
+        dominant = None
+        if kernels:
+            dk = max(kernels, key=lambda k: kernels[k]["kernel_ms_total"])
+            dominant = dict(kernels[dk], family=dk)
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC pass (tools/pmc_traffic.py), bytes per launch
-        if os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC passes (tools/pmc_traffic.py), bytes per launch
+        if os.path.exists(tpath) and dominant is not None:
             try:
-                traffic = json.load(open(tpath)).get(args.roofline_kernel, {}).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                key = {"gemm256_fwd": "fc1", "gemm256_wgrad": "wgrad", "gemm256_dgrad": "dgrad", "attention_fwd": "attn_fwd",
+                       "attention_bwd": "attn_bwd_dq"}.get(dominant["family"])
+                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        more = {}
-        for k in KernelTimer.TARGET:
-            if k != args.roofline_kernel:
-                nn_, ms_, tf_ = timer.result(k)
-                more[k] = {"launches": nn_, "kernel_ms_total": round(ms_, 3), "achieved": round(tf_, 2), "frac": round(tf_ / peak, 4)}
+        achieved = ips / n_ranks * FLOP_BLOCKS_FWD_BWD / 1e12
         out = {
             "metric": "images/sec (896x448 pairs) ViT-L fwd+bwd",
-            "value": round(ips, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(ips, 3), "unit": "images/sec", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": "painter_vit_large_patch16_input896x448 %s batch=%d/GPU fwd+bwd on %dxMI355X (BASELINE configs[1])"
-                                   % (args.dtype, args.batch, world),
-                       "global_batch": world * args.batch, "image": "896x448x3 stitched pair", "tokens": cfg.L,
-                       "mode": "eval" if args.eval else "train (DropPath 0.1)", "parallelism": "dp%d" % world,
-                       "grad_allreduce": "RCCL bucketed, overlapped with backward" if world > 1 else "n/a"},
-            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4),
-                         "traffic": traffic, "kernel": kname, "launches": n, "kernel_ms_total": round(kms, 3),
-                         "avg_us": round(kms / max(n, 1) * 1e3, 2), "other_kernels": more},
-            "model_mfma_frac": round(ips / world * FLOP_BLOCKS_FWD_BWD / (peak * 1e12), 4),
-            "model_tflops_per_gpu": round(ips / world * FLOP_MODEL_FWD_BWD / 1e12, 2),
+                                   % (args.dtype, args.batch, n_ranks),
+                       "global_batch": n_ranks * args.batch, "image": "896x448x3 stitched pair", "tokens": cfg.L,
+                       "mode": "eval" if args.eval else "train (DropPath 0.1)", "parallelism": "dp%d" % n_ranks,
+                       "rccl_ranks": n_ranks if distributed else 0,
+                       "grad_allreduce": "RCCL bucketed, overlapped with backward" if n_ranks > 1 else "n/a"},
+            "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                         "definition": "images/s/GPU x 4.034 TFLOP (attention + MLP blocks, fwd+bwd; SURVEY.md 8d) / dense bf16 MFMA peak",
+                         "whole_model_achieved": round(ips / n_ranks * FLOP_MODEL_FWD_BWD / 1e12, 2),
+                         "whole_model_frac": round(ips / n_ranks * FLOP_MODEL_FWD_BWD / 1e12 / peak, 4),
+                         "traffic": traffic, "dominant_kernel": dominant, "kernels": kernels,
+                         "profiled_pass": "separate pass of %d steps after the timed region, HIP events per launch, one stream" % args.profile_steps},
             "loss": round(lossv, 6),
         }
-        if world == 1 and args.dtype == "bf16":
+        if n_ranks == 1 and args.dtype == "bf16" and not args.no_optimizer:
             out["optimizer_step"] = optimizer_step_ms(model, step)
-        if world == 1 and not args.no_cpu_baseline:
+        if n_ranks == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1 or parallel._SELFTEST:
+    if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

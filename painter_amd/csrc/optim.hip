@@ -95,8 +95,11 @@ DEVI void adamw1(float& p, float& m, float& v, float g, float lr, float wd, floa
     p = p - step_size * (m / denom);
 }
 
+// norm_info[0] is the sum of squares of the gradients AS STORED (still loss-scaled): with a large loss scale it can overflow fp32
+// although no single element did.  torch unscales before it takes the norm and has no such window; here an overflowed (or NaN) sum
+// counts as "found inf": the step is skipped and GradScaler backs the scale off, instead of clipping every gradient to zero.
 DEVI bool skip_step(const float* norm_info, const float* found_inf) {
-    return (found_inf != nullptr && found_inf[0] != 0.f) || (norm_info != nullptr && norm_info[1] != 0.f);
+    return (found_inf != nullptr && found_inf[0] != 0.f) || (norm_info != nullptr && (norm_info[1] != 0.f || !(norm_info[0] <= 3.0e38f)));
 }
 // steps[g] += 1 for every group that takes part in this step, unless the step is skipped (inf/nan): the per-group step count
 // lives on the device so that the skip needs no host round trip (torch's capturable / fused AdamW keeps it there too)

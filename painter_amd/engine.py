@@ -66,6 +66,9 @@ class HotPathConfig:
         if self.H != 2 * self.W: err.append("img_size must be (2W, W) (patchify asserts H == 2W, models_painter.py:361)")
         if self.merge_idx >= self.depth or len(set(self.taps)) != 4 or self.taps[-1] != self.depth - 1:
             err.append("depth %d incompatible with merge/tap schedule" % self.depth)
+        if self.merge_idx in self.taps or min(self.taps) < self.merge_idx:
+            # the backward handles a block that is a feature tap OR the stream merge, and taps are taken on the merged stream
+            err.append("depth %d puts a feature tap at or before the stream merge (block %d)" % (self.depth, self.merge_idx))
         if err:
             raise NotImplementedError("painter_amd HIP path: " + "; ".join(err))
 

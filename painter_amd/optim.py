@@ -33,6 +33,10 @@ class _Groups(ctypes.Structure):
 
 class AdamW(torch.optim.Optimizer):
     _step_supports_amp_scaling = True        # torch GradScaler then hands grad_scale / found_inf over instead of unscaling itself
+    # class-level defaults: torch's GradScaler.step() sets these on the instance and DELETES them afterwards, so a later plain
+    # opt.step() must still find the names
+    grad_scale = None
+    found_inf = None
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0) or weight_decay < 0.0:
@@ -44,8 +48,6 @@ class AdamW(torch.optim.Optimizer):
         e = {g["eps"] for g in self.param_groups}
         if len(b) != 1 or len(e) != 1:
             raise NotImplementedError("betas and eps must be shared by all groups (they are in the reference)")
-        self.grad_scale = None
-        self.found_inf = None
         self._norm_info = None
         self._cached = None
         self._tab_dev = None
@@ -71,6 +73,20 @@ class AdamW(torch.optim.Optimizer):
             st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
             st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
         return st
+
+    def state_dict(self):
+        """torch.optim layout.  `step` is stored per parameter as its own 0-d tensor: inside this class the steps of a group are
+        views of one element of a shared device array, and torch.save would keep that aliasing -- a torch.optim.AdamW resuming
+        from such a checkpoint would then advance the shared element once per parameter of the group."""
+        sd = super().state_dict()
+        for st in sd["state"].values():
+            if torch.is_tensor(st.get("step")):
+                st["step"] = st["step"].detach().clone().reshape(())
+        return sd
+
+    def zero_grad(self, set_to_none=True):
+        self._cached, self._norm_info = None, None            # the cached table points at the gradients being dropped
+        return super().zero_grad(set_to_none=set_to_none)
 
     def load_state_dict(self, state_dict):
         """Checkpoints written by torch.optim.AdamW or by this class: re-home the per-parameter `step` scalars in the per-group
@@ -141,8 +157,11 @@ class AdamW(torch.optim.Optimizer):
         ws = ops.workspace(lib.pa_grad_sumsq_workspace_bytes(nchunks), dev, slot=2)
         check(lib.pa_grad_sumsq(tab.data_ptr(), nt, nchunks, out.data_ptr(), ws.data_ptr(), ops.stream()), "pa_grad_sumsq")
         self._norm_info = out
-        self._cached = (tab, nt, nchunks, dev)
+        self._cached = (tab, nt, nchunks, dev, self._grad_ptrs())
         return out
+
+    def _grad_ptrs(self):
+        return tuple(0 if p.grad is None else p.grad.data_ptr() for g in self.param_groups for p in g["params"] if p.requires_grad)
 
     @torch.no_grad()
     def step(self, closure=None, *, grad_scale=None, found_inf=None, max_norm=None):
@@ -152,14 +171,19 @@ class AdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        grad_scale = grad_scale if grad_scale is not None else self.grad_scale
-        found_inf = found_inf if found_inf is not None else self.found_inf
+        grad_scale = grad_scale if grad_scale is not None else getattr(self, "grad_scale", None)
+        found_inf = found_inf if found_inf is not None else getattr(self, "found_inf", None)
         norm_info = None
         if max_norm is not None and max_norm > 0:
             if self._norm_info is None:
                 self.grad_sumsq()
             norm_info = self._norm_info
-        tab, nt, nchunks, dev = self._cached if self._cached is not None else self._table()
+        if self._cached is not None and self._cached[4] != self._grad_ptrs():
+            self._cached, self._norm_info, norm_info = None, None, None      # gradients were replaced since grad_sumsq(): start over
+            if max_norm is not None and max_norm > 0:
+                self.grad_sumsq()
+                norm_info = self._norm_info
+        tab, nt, nchunks, dev = self._cached[:4] if self._cached is not None else self._table()
         self._cached, self._norm_info = None, None
         if tab is None:
             return loss
@@ -204,7 +228,8 @@ class NativeScalerWithGradNormCount:
         scale = self._scaler._scale if self._scaler.is_enabled() else None
         if scale is None:
             scale = torch.ones((), dtype=torch.float32, device=info.device)
-        found_inf = (info[1:2] != 0).to(torch.float32)               # scalar plumbing for GradScaler.update()
+        # scalar plumbing for GradScaler.update(); an overflowed sum of squares counts as inf (pa_adamw_step skips on it too)
+        found_inf = ((info[1:2] != 0) | ~torch.isfinite(info[0:1])).to(torch.float32)
         norm = torch.sqrt(info[0]) / scale.reshape(())
         optimizer.step(grad_scale=scale, found_inf=found_inf, max_norm=clip_grad)    # pass 2
         if self._scaler.is_enabled():

@@ -5,37 +5,39 @@ One process per GPU, `torch.distributed` backend "nccl" (= RCCL on ROCm, xGMI be
 path shards by samples, so the only exchange is the gradient all-reduce: `GradSync` is called by the engine's
 backward as soon as a bucket of parameter gradients has been ENQUEUED (decoder head first, then blocks 23 -> 0, then
 the patch/token parameters) and starts asynchronous all-reduce(AVG)s: the weight matrices in place (no flattening copy), the
-bucket's small tensors flattened into one message.  RCCL runs it on its own stream, ordered after the producing kernels, so the exchange of bucket k
-overlaps the backward kernels of bucket k+1.  `finish()` makes the compute stream wait for all buckets and hands the
-averaged gradients back (in place, or as views into the flat message).
+bucket's small tensors flattened into one message.  RCCL runs it on its own stream, ordered after the producing kernels, so the
+exchange of bucket k overlaps the backward kernels of bucket k+1.  `finish()` makes the compute stream wait for all buckets and
+hands the averaged gradients back (in place, or as views into the flat message).
 
 Bucket = one transformer block (~12.6 M params = 50 MB fp32) -- large messages because a ring/tree over
 point-to-point xGMI links is per-link bandwidth bound, not latency bound; decoder_embed's 268 MB gradient is its own
 bucket so it is on the wire while the blocks are still being differentiated.
 
-Gradient accumulation: construct with `every=k` (or call `set_sync(False)`) to skip the exchange on non-update
-micro-steps -- the reference all-reduces on every micro-step because it never uses no_sync() (engine_train.py:85-90);
-the sum of micro-gradients is identical either way.
+Gradient accumulation: the exchange runs on EVERY micro-step, exactly like the reference (its DDP model is never put under
+no_sync(), engine_train.py:85-90).  What is reduced is the micro-step's own gradient, before autograd adds it to `p.grad`; the sum
+of averaged micro-gradients equals the average of the summed ones, so replicas stay identical.  (There is deliberately no switch
+to skip micro-steps: skipping would leave the skipped micro-gradients rank-local and replicas would drift apart.)
+
+Replica start: DistributedDataParallel broadcasts rank 0's parameters when it wraps a module; a run that installs `GradSync`
+instead of the wrapper must call `broadcast_parameters(model)` once (the reference seeds every rank differently, main_train.py:190).
 """
+import os
+import warnings
+
 import torch
 import torch.distributed as dist
 
 
 # PAINTER_AMD_DDP_SELFTEST=1: run the exchange even in a 1-rank group (exercises RCCL init, AVG all-reduce, the stream ordering
 # and the in-place / flattened paths on a single-GPU box; the result must equal the local gradient)
-import os as _os
-_SELFTEST = _os.environ.get("PAINTER_AMD_DDP_SELFTEST", "0") == "1"
+_SELFTEST = os.environ.get("PAINTER_AMD_DDP_SELFTEST", "0") == "1"
 
 
 class GradSync:
     def __init__(self, process_group=None, average=True):
         self.group = process_group
         self.average = average
-        self.enabled = True
         self._pending = []
-
-    def set_sync(self, enabled: bool):
-        self.enabled = bool(enabled)
 
     @property
     def world_size(self):
@@ -54,7 +56,7 @@ class GradSync:
         """Gradients `names` of dict G are enqueued on the current stream: start their all-reduce.  Weight matrices (>= 1 M
         elements: 4-268 MB messages, large enough to run at link bandwidth) are reduced in place; the bucket's small tensors
         (biases, LayerNorm, rel-pos tables) are flattened into one message and replaced by views of it."""
-        if not self.enabled or (self.world_size == 1 and not _SELFTEST):
+        if self.world_size == 1 and not _SELFTEST:
             return
         small = []
         for n in names:
@@ -82,13 +84,34 @@ class GradSync:
         self._pending = []
 
 
+def broadcast_parameters(module, src=0, process_group=None):
+    """Every rank adopts rank `src`'s parameters and buffers -- what the DDP wrapper does at construction
+    (Painter/main_train.py:340); needed once when GradSync replaces the wrapper."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t.data, src=src, group=process_group)
+
+
+def _ipc_env():
+    """The host driver of the MI355X boxes only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's P2P set-up fails
+    with `hipIpcGetMemHandle: invalid argument`.  HSA reads the variable when the runtime initialises, so it has to be in the
+    environment before the first HIP call of the process (painter_amd/__init__.py sets it at import as well)."""
+    if "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ:
+        os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            warnings.warn("HSA_ENABLE_IPC_MODE_LEGACY was unset and the HIP runtime is already initialised: export "
+                          "HSA_ENABLE_IPC_MODE_LEGACY=0 before starting multi-GPU runs (INTEGRATION.md section 7)")
+
+
 def init_distributed(backend=None):
     """env:// rendezvous as torchrun sets it up (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT);
-    mirrors util/misc.py:217-249 without the SLURM/OMPI parsing."""
-    import os
+    mirrors util/misc.py:217-249 without the SLURM/OMPI parsing.  -> (rank, local_rank, world_size)"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and not _SELFTEST:
         return 0, 0, 1
+    _ipc_env()
     os.environ.setdefault("RANK", "0")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29517")

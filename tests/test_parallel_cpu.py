@@ -1,6 +1,13 @@
-"""world_size-2 gloo tests of the data-parallel path: GradSync must deliver, on every rank, the
-average of the per-rank gradients (== the gradient of the global batch for a mean-reduced loss), with buckets handed
-over out of order, and the skip-on-accumulation switch must leave gradients local."""
+"""world_size-2 gloo tests of the data-parallel path.
+
+1. GradSync must deliver, on every rank, the average of the per-rank gradients, with buckets handed over out of order (in-place
+   path for big tensors, flattened message for small ones).
+2. The same with REAL model gradients: each rank differentiates the tiny Painter (the CPU oracle's autograd is the producer, the HIP
+   path needs a GPU) on its own sample, hands the gradients to GradSync bucket by bucket in the engine's order (decoder first, blocks
+   last to first, token/patch parameters), accumulates two micro-steps as engine_train.py:85-90 does, and must end up with the
+   gradient of the global batch -- bit-equal across ranks, equal to the mean of the per-rank gradients to fp32 rounding and to the
+   single-process big-batch gradient up to the loss's `+ 1e-2` denominator term (models_painter.py:462).
+3. broadcast_parameters makes replicas that were seeded differently identical (main_train.py:190 seeds seed + rank)."""
 import os
 import socket
 
@@ -17,16 +24,21 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _init(rank, world, port):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
     from painter_amd import parallel
     r, _, w = parallel.init_distributed(backend="gloo")
     assert (r, w) == (rank, world)
+    assert os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY") == "0"
+    return parallel
+
+
+def _worker(rank, world, port, q):
+    parallel = _init(rank, world, port)
     g = torch.Generator().manual_seed(100 + rank)
     names = ["decoder_embed.weight", "blocks.1.attn.qkv.weight", "blocks.1.attn.rel_pos_h", "blocks.0.mlp.fc1.bias", "pos_embed"]
     shapes = [(16, 8), (12, 4), (5, 4), (7,), (1, 3, 4)]
     G = {n: torch.randn(s, generator=g) for n, s in zip(names, shapes)}
-    local = {n: t.clone() for n, t in G.items()}
     sync = parallel.GradSync()
     sync.BIG = 40                       # (16, 8) and (12, 4) take the in-place path, the rest the flattened small-tensor message
     sync.ready(G, names[:1])            # decoder bucket first, as the engine's backward does
@@ -43,26 +55,98 @@ def _worker(rank, world, port, q):
             ref += vals[n]
         ref /= world
         ok &= bool(torch.allclose(G[n], ref, atol=1e-6)) and G[n].shape == torch.Size(s)
-    # accumulation micro-step: no exchange, gradients stay local
-    G2 = {n: t.clone() for n, t in local.items()}
-    sync.set_sync(False)
-    sync.ready(G2, names)
-    sync.finish()
-    ok &= all(torch.equal(G2[n], local[n]) for n in names)
+    ok &= not hasattr(sync, "set_sync")          # there is no way to skip a micro-step's exchange (replicas would diverge)
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gradsync_world2_gloo():
-    world, port = 2, _free_port()
+def _bucket_order(names, depth):
+    """The order in which engine.HotPath.backward hands gradients to GradSync.ready()."""
+    order = [["decoder_embed.weight", "decoder_embed.bias"], [n for n in names if n.startswith("decoder_pred.")]]
+    for i in reversed(range(depth)):
+        order.append([n for n in names if n.startswith("blocks.%d." % i)])
+    order.append(["norm.weight", "norm.bias", "patch_embed.proj.weight", "patch_embed.proj.bias", "pos_embed", "segment_token_x",
+                  "segment_token_y", "mask_token"])
+    assert sorted(sum(order, [])) == sorted(names)
+    return order
+
+
+def _model_grads(P0, cfg, seeds):
+    """Gradient dict of the tiny Painter oracle on the batch made of the samples `seeds` (eval mode)."""
+    from oracle import painter_oracle as O
+    P = {k: v.clone().requires_grad_(True) for k, v in P0.items()}
+    parts = [O.synthetic_batch(cfg, 1, s, "random") for s in seeds]
+    imgs, tgts, mask, valid = [torch.cat([p_[i] for p_ in parts]) for i in range(4)]
+    loss, _, _ = O.forward(P, cfg, imgs, tgts, mask, valid)
+    loss.backward()
+    return {k: v.grad.clone() for k, v in P.items()}
+
+
+def _worker_model(rank, world, port, q):
+    parallel = _init(rank, world, port)
+    from oracle import painter_oracle as O
+    torch.set_num_threads(2)
+    cfg = O.tiny_config()
+    # replicas start from different seeds (main_train.py:190) and are made identical by the broadcast
+    P0 = O.random_params(cfg, 50 + rank)
+    holder = torch.nn.ParameterDict({k.replace(".", "/"): torch.nn.Parameter(v) for k, v in P0.items()})
+    parallel.broadcast_parameters(holder)
+    P0 = {k.replace("/", "."): v.detach() for k, v in holder.items()}
+    ref0 = O.random_params(cfg, 50)
+    same = all(torch.equal(P0[k], ref0[k]) for k in ref0)
+    sync = parallel.GradSync()
+    sync.BIG = 4096
+    names = list(P0.keys())
+    acc = {n: torch.zeros_like(t) for n, t in P0.items()}
+    micro = [[10 + rank], [20 + rank]]                       # two accumulation micro-steps, one sample per rank each
+    for seeds in micro:
+        G = _model_grads(P0, cfg, seeds)
+        for bucket in _bucket_order(names, cfg.depth):
+            sync.ready(G, bucket)
+        sync.finish()
+        for n in names:
+            acc[n] += G[n]                                   # what autograd does with the returned gradients
+    q.put((rank, same, {n: t.numpy().copy() for n, t in acc.items()}))     # by value (tensors would travel as shm handles)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(target, world=2):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
+    res = [q.get(timeout=300) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(r for r, _ in res) == [0, 1]
+    return sorted(res, key=lambda r: r[0])
+
+
+def test_gradsync_world2_gloo():
+    res = _run(_worker)
+    assert [r for r, _ in res] == [0, 1]
     assert all(ok for _, ok in res), res
+
+
+def test_gradsync_world2_model_gradients_with_accumulation():
+    from oracle import painter_oracle as O
+    res = _run(_worker_model)
+    assert all(same for _, same, _ in res), "broadcast_parameters did not make the replicas identical"
+    g0, g1 = ({n: torch.from_numpy(a) for n, a in res[r][2].items()} for r in range(2))
+    cfg = O.tiny_config()
+    P0 = O.random_params(cfg, 50)
+    per_rank = [[_model_grads(P0, cfg, [10 + r]), _model_grads(P0, cfg, [20 + r])] for r in range(2)]
+    big = [_model_grads(P0, cfg, [10, 11]), _model_grads(P0, cfg, [20, 21])]
+    worst_mean, worst_big = 0.0, 0.0
+    for n in g0:
+        assert torch.equal(g0[n], g1[n]), n                  # replicas hold bit-identical accumulated gradients
+        mean = sum((per_rank[0][m][n] + per_rank[1][m][n]) * 0.5 for m in range(2))
+        bigb = big[0][n] + big[1][n]
+        den = mean.abs().max().clamp_min(1e-12)
+        worst_mean = max(worst_mean, float((g0[n] - mean).abs().max() / den))
+        worst_big = max(worst_big, float((g0[n] - bigb).abs().max() / bigb.abs().max().clamp_min(1e-12)))
+    assert worst_mean < 1e-6, worst_mean
+    assert worst_big < 1e-4, worst_big                       # only the `+ 1e-2` in the loss denominator separates the two
