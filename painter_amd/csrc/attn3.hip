@@ -30,109 +30,12 @@
 // The backward's prep kernel fills the lse rows and -Delta; dQ reads its own rows once, dKV streams the kw part and the <= 8 kh rows
 // its workgroup needs with every query tile (10.7 KB per tile instead of attn2's 19 KB).  Because forward and backward contract the
 // very same bf16 T entries, P is recomputed in the backward from exactly the logits the forward saw.
-#include "attn_tile.h"
+#include "attn3_common.h"
 #include "../../include/painter_hip.h"
 #include "attn3.h"
 #include <cstdlib>
-#include <type_traits>
 
 namespace a3 {
-using namespace atile;
-
-constexpr int WP = 28, PH = 7, RPP = 8;       // key-row width; 32-key tile phases per period; key rows per period (7 * 32 = 8 * 28)
-constexpr int EIMG = 2048;                    // one one-hot image: [32 keys][32 slots] bf16
-constexpr float THR = 6.0f;
-
-__host__ __device__ inline int ttile_bytes(int Hp) { return (2048 + (Hp + 2) * 64 + 128 + 255) & ~255; }
-// physical slot of kw inside a 32-slot T row / E row: k-step 0 = kw 0..15; k-step 1: half-wave g holds kw 16+6g .. 21+6g in t = 0..5 and
-// the window slots 2g, 2g+1 in t = 6, 7
-DEVI int kw_phys(int kw) { return kw < 22 ? kw : kw + 2; }
-
-// one-hot images of the 7 tile phases.  Row i = key 32 p + i of a period: kw = (4 p + i) % 28, key row (relative) p + ((4 p + i) >= 28).
-// 16-byte chunk c = 2 s + g of a row is stored at c ^ ((i >> 2) & 3): conflict-free for the row reads (ds_read_b128) and for the
-// transposing reads (which always see 4 consecutive rows of one 4-row group).
-DEVI void build_eimg(unsigned char* eimg, int tid) {
-    for (int idx = tid; idx < PH * 512; idx += NT) {
-        const int ph = idx >> 9, i = (idx >> 4) & 31, dw = idx & 15;
-        const int c = dw >> 2, s = c >> 1, g = c & 1;
-        const int a = 4 * ph + i, kw = a % WP, khr = ph + (a >= WP ? 1 : 0);
-        uint32_t w = 0;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int t = (dw & 3) * 2 + e;
-            bool one;
-            if (s == 0) one = kw == 8 * g + t;
-            else if (t < 6) one = kw == 16 + 6 * g + t;
-            else one = (khr & 3) == 2 * g + (t - 6);
-            if (one) w |= 0x3F80u << (16 * e);
-        }
-        *reinterpret_cast<uint32_t*>(eimg + ph * EIMG + i * 64 + ((c ^ ((i >> 2) & 3)) << 4) + (dw & 3) * 4) = w;
-    }
-}
-struct EAddr {
-    int row[2];    // [32 rows][64 B] image, chunk-swizzled as above: 16-byte row fragment of k-step s (lane = row)
-    int tr[2];     // transposed fragment (rows = slots, contraction over the image's rows): lo / hi; k-step 1 = + 1024
-    DEVI void init(int lane) {
-        const int i = lane & 31, g = lane >> 5;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) row[s] = i * 64 + (((2 * s + g) ^ ((i >> 2) & 3)) << 4);
-        const int ii = lane & 15, half = (lane >> 4) & 1;
-#pragma unroll
-        for (int hi = 0; hi < 2; ++hi) {
-            const int r = 4 * g + (ii >> 2) + 8 * hi;
-            tr[hi] = r * 64 + (((2 * half + ((ii & 3) >> 1)) ^ ((r >> 2) & 3)) << 4) + (ii & 1) * 8;
-        }
-    }
-};
-DEVI bf16x8 efrag(const unsigned char* img, const EAddr& e, int s) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(img + e.row[s]));
-}
-DEVI bf16x8 etrfrag(const unsigned char* img, const EAddr& e, int s) {
-    const u32x2 l = ldtr(img + e.tr[0] + s * 1024), h = ldtr(img + e.tr[1] + s * 1024);
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(l, h, 0, 1, 2, 3));
-}
-DEVI bf16x8 as_frag(const uint4& v) { return __builtin_bit_cast(bf16x8, v); }
-DEVI f32x16 zero16() {
-    f32x16 z;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = 0.f;
-    return z;
-}
-// window slot update: 16 bits of `w` <- the kh-table entry at p (every lane of the wave, see the file header)
-template <int HALF> DEVI void win_set(uint32_t& w, const unsigned char* p) {
-    const uint32_t v = *reinterpret_cast<const uint16_t*>(p);
-    w = HALF ? ((w & 0xffffu) | (v << 16)) : ((w & 0xffff0000u) | v);
-}
-// eacc register (half-wave 1) that holds window slot `slot`: rows 22, 23, 30, 31 of the D tile
-DEVI constexpr int win_reg(int slot) { return slot == 0 ? 10 : slot == 1 ? 11 : slot == 2 ? 14 : 15; }
-
-// T of this lane's query row from G^T = Rcat . Q^T: kw part -> twimg[q][32 slots] (bf16, window slots stay zero),
-// kh part -> thT[kh][q] (bf16).  Both scaled by 1 / scale, so that logits = scale * log2e * (q.k + T.E).
-DEVI void build_tables3(unsigned char* twimg, unsigned char* thT, const bf16* rcat, int NRP, const bf16x8 (&qf)[4], int qh, int qw, int Hp,
-                        float inv_scale, int lane) {
-    const int g = lane >> 5, ql = lane & 31;
-    *reinterpret_cast<uint4*>(twimg + lane * 32) = zero4();
-    *reinterpret_cast<uint4*>(twimg + lane * 32 + 16) = zero4();
-    for (int rbk = 0; rbk < NRP / 32; ++rbk) {
-        f32x16 acc = zero16();
-        const bf16* rp = rcat + (size_t)(rbk * 32 + ql) * ATT_HD;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) acc = mfma(gfrag(rp, s, g), qf[s], acc);
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int r = rbk * 32 + acc_row(reg, lane);
-            const bf16 v = (bf16)(acc[reg] * inv_scale);
-            if (r < 2 * Hp - 1) {
-                const int kh = qh + Hp - 1 - r;
-                if (kh >= 0 && kh < Hp) *reinterpret_cast<bf16*>(thT + kh * 64 + ql * 2) = v;
-            } else {
-                const int rr = r - (2 * Hp - 1);
-                const int kw = qw + WP - 1 - rr;
-                if (rr < 2 * WP - 1 && kw >= 0 && kw < WP) *reinterpret_cast<bf16*>(twimg + ql * 64 + kw_phys(kw) * 2) = v;
-            }
-        }
-    }
-}
 
 // =============================================================================================== forward
 // LDS: [K img | V img] x STAGES | thT 4 waves x [Hp][32 q] bf16 | 7 one-hot images (the per-wave T rows alias them during the prologue)
@@ -644,8 +547,13 @@ __global__ void prep_kernel(const float* __restrict__ lse, const float* __restri
 
 }   // namespace a3
 
-// PA_ATTN3=0 / pa_attn_set_generation(2): keep the generation-2 kernels for every grid (A/B runs, cross-generation tests)
+// PA_ATTN3=0 / pa_attn_set_generation(2): keep the generation-2 kernels for every grid (A/B runs, cross-generation tests);
+// PA_ATTN3_PAIRED=0 / pa_attn_set_generation(3): generation 3 in its 4-wave build instead of the paired 8-wave build (attn3p.hip)
 static int g_attn_generation = 0;
+static bool attn3_paired() {
+    static const int on = [] { const char* e = getenv("PA_ATTN3_PAIRED"); return e ? atoi(e) : 1; }();
+    return on && g_attn_generation != 3;
+}
 extern "C" int pa_attn_set_generation(int generation) {
     if (generation != 0 && generation != 2 && generation != 3) return (int)hipErrorInvalidValue;
     g_attn_generation = generation;
@@ -667,6 +575,7 @@ static int a3_xcd_map_on() {
 int attn3_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t ldo, float* lse, void* tables, int Bn, int L, int H,
               int Hp, int Wp, float scale, hipStream_t st) {
     using namespace a3;
+    if (attn3_paired()) return attn3p_fwd(qkv, ldq, rcat, out, ldo, lse, tables, Bn, L, H, Hp, Wp, scale, st);
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
     // PA_ATTN3_FWD_STAGES: 1 (default) = single K/V stage, 4 workgroups per CU; 2 = double-buffered, one barrier per tile
     static const int stages = [] { const char* v = getenv("PA_ATTN3_FWD_STAGES"); return v ? atoi(v) : 1; }();
@@ -683,6 +592,7 @@ int attn3_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t
 int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const float* delta,
               void* tables, bf16* dqkv, bf16* dG, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st) {
     using namespace a3;
+    if (attn3_paired()) return attn3p_bwd(qkv, ldq, rcatT, dout, lddo, lse, delta, tables, dqkv, dG, Bn, L, H, Hp, Wp, scale, st);
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
     const int nblk = (L / 32 + NW - 1) / NW;
     unsigned char* tb = reinterpret_cast<unsigned char*>(tables);

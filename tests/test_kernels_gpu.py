@@ -172,7 +172,8 @@ def attn_reference(qkv, rel_h, rel_w, B, L, H, Hp, Wp, scale):
 
 @pytest.fixture
 def attn_generation():
-    """pa_attn_set_generation for the duration of one test (0 = newest kernels that cover the grid, 2 = never generation 3)."""
+    """pa_attn_set_generation for the duration of one test (0 = newest kernels that cover the grid: generation 3, paired 8-wave build;
+    3 = generation 3, 4-wave build; 2 = never generation 3)."""
     from painter_amd._lib import lib
 
     def set_(g):
@@ -181,12 +182,12 @@ def attn_generation():
     lib.pa_attn_set_generation(0)
 
 
-@pytest.mark.parametrize("gen_", [0, 2])
+@pytest.mark.parametrize("gen_", [0, 3, 2])
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,Hp,Wp", [(1, 2, 8, 4), (2, 2, 56, 28), (1, 1, 16, 8), (1, 2, 8, 12), (2, 1, 8, 20), (1, 2, 16, 16),
                                         (1, 1, 8, 24), (1, 3, 16, 28), (1, 1, 8, 28)])
 def test_attn_fwd(T, B, H, Hp, Wp, gen_, attn_generation):
-    if gen_ == 2 and not (T == torch.bfloat16 and Wp == 28):
+    if gen_ != 0 and not (T == torch.bfloat16 and Wp == 28):
         pytest.skip("generation switch only matters where generation 3 applies")
     attn_generation(gen_)
     L = Hp * Wp
@@ -202,12 +203,12 @@ def test_attn_fwd(T, B, H, Hp, Wp, gen_, attn_generation):
     assert e_o < (2e-5 if T == torch.float32 else 2e-2), (e_o, e_l)
 
 
-@pytest.mark.parametrize("gen_", [0, 2])
+@pytest.mark.parametrize("gen_", [0, 3, 2])
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("B,H,Hp,Wp", [(1, 2, 8, 4), (2, 2, 56, 28), (3, 1, 16, 8), (1, 2, 8, 12), (2, 1, 8, 20), (1, 2, 16, 16),
                                         (1, 1, 8, 24), (1, 3, 16, 28), (1, 1, 8, 28)])
 def test_attn_bwd(T, B, H, Hp, Wp, gen_, attn_generation):
-    if gen_ == 2 and not (T == torch.bfloat16 and Wp == 28):
+    if gen_ != 0 and not (T == torch.bfloat16 and Wp == 28):
         pytest.skip("generation switch only matters where generation 3 applies")
     attn_generation(gen_)
     L = Hp * Wp
@@ -220,7 +221,7 @@ def test_attn_bwd(T, B, H, Hp, Wp, gen_, attn_generation):
     rcatT = ops.relpos_pack_t(rel_h, rel_w, Hp, Wp, T)
     assert torch.equal(rcatT.t().contiguous(), rcat)
     out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
-    assert (tables is not None) == (gen_ == 0 and T == torch.bfloat16 and Wp == 28 and Hp % 8 == 0)
+    assert (tables is not None) == (gen_ != 2 and T == torch.bfloat16 and Wp == 28 and Hp % 8 == 0)
     dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables)
     q64 = qkv.double().clone().requires_grad_(True)
     rh64 = rcat[:nh].double().clone().requires_grad_(True)
@@ -283,8 +284,10 @@ def _attn3_inputs(B, H, Hp, Wp, spike=False):
     return L, qkv, rcat, rcatT, dout
 
 
-def test_attn3_bf16_spiked_key_rebase():
+@pytest.mark.parametrize("gen_", [0, 3])
+def test_attn3_bf16_spiked_key_rebase(gen_, attn_generation):
     """generation-3 forward + backward with a late, large logit (forces the running-max re-base) vs the fp64 reference."""
+    attn_generation(gen_)
     B, H, Hp, Wp = 1, 1, 8, 28
     L, qkv, rcat, rcatT, dout = _attn3_inputs(B, H, Hp, Wp, spike=True)
     out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
@@ -305,17 +308,23 @@ def test_attn_generations_agree(attn_generation):
     B, H, Hp, Wp = 2, 2, 56, 28
     L, qkv, rcat, rcatT, dout = _attn3_inputs(B, H, Hp, Wp)
     res = {}
-    for g_ in (2, 0):
+    for g_ in (2, 3, 0):
         attn_generation(g_)
         out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
         dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables)
         res[g_] = (out.float(), lse, dqkv.float(), drcat)
-    assert relerr(res[0][1], res[2][1]) < 4e-3          # each is ~1.3e-3 from the fp64 reference (bf16 bias tables), in different directions
-    for a, b in zip(res[0], res[2]):
-        assert relerr(a, b) < 1.5e-2, [relerr(x, y) for x, y in zip(res[0], res[2])]
+    for g3 in (0, 3):
+        assert relerr(res[g3][1], res[2][1]) < 4e-3      # each is ~1.3e-3 from the fp64 reference (bf16 bias tables), in different directions
+        for a, b in zip(res[g3], res[2]):
+            assert relerr(a, b) < 1.5e-2, [relerr(x, y) for x, y in zip(res[g3], res[2])]
+    # the two builds of generation 3 contract the same operands; only the order of a few fp32 additions differs
+    for a, b in zip(res[0], res[3]):
+        assert relerr(a, b) < 2e-3, [relerr(x, y) for x, y in zip(res[0], res[3])]
 
 
-def test_attn3_deterministic():
+@pytest.mark.parametrize("gen_", [0, 3])
+def test_attn3_deterministic(gen_, attn_generation):
+    attn_generation(gen_)
     B, H, Hp, Wp = 1, 2, 16, 28
     L, qkv, rcat, rcatT, dout = _attn3_inputs(B, H, Hp, Wp)
     runs = []
