@@ -83,8 +83,8 @@ int pa_relpos_pack(int dtype, const float* rel_pos_h, const float* rel_pos_w, vo
  * tables: NULL (inference), or pa_attn_tables_bytes() of device memory that receives the per-query bias tables the
  * backward reuses (only the 28-token-wide bf16 kernels write it; the size is 0 for every other case). */
 int64_t pa_attn_tables_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp);
-/* 0 = newest kernels that cover the grid (default), 3 = generation 3 in its 4-wave build, 2 = never use the 28-token-wide
- * generation-3 kernels (diagnostics, A/B, cross-generation tests) */
+/* 0 = default kernels for the grid (generation 3, 4-wave build, where it applies), 3 = the same explicitly, 4 = generation 3 in
+ * its paired 8-wave build, 2 = never use the 28-token-wide generation-3 kernels (diagnostics, A/B, cross-generation tests) */
 int pa_attn_set_generation(int generation);
 int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse,
                 void* tables, int batch, int L, int heads, int Hp, int Wp, float scale, hipStream_t stream);

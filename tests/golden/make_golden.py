@@ -152,13 +152,124 @@ def case_vit_large(out, prefix):
     grad_digest([(n, p.grad) for n, p in model.named_parameters()], out, prefix)
 
 
+def _record_droppath(rec):
+    """Replace the DropPath stand-in's forward by one that records the per-sample factors it draws (timm 0.3.2 semantics)."""
+    orig = ref_import._DropPath.forward
+
+    def fwd(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1 - self.drop_prob
+        shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+        rt = (keep + torch.rand(shape, dtype=x.dtype, device=x.device)).floor_()
+        rec.append((rt.reshape(-1) / keep).clone())
+        return x.div(keep) * rt
+    ref_import._DropPath.forward = fwd
+    return orig
+
+
+def case_vit_large_b8_train(out, prefix, batch=8):
+    """BASELINE configs[1]: ViT-L 896x448, B = 8, TRAIN mode (DropPath 0.1), forward + backward.
+
+    The unmodified reference at B = 8 needs > 100 GB (it keeps every fp32 attention matrix), the build container has 62 GB.  Samples
+    do not interact in Painter.forward except through the loss normaliser (models_painter.py:462: sum(loss * mask) / (sum(mask) + 1e-2)
+    over the whole batch) and DropPath draws one factor per sample and residual branch, so the B = 8 result is assembled from eight
+    B = 1 runs of the unmodified reference:  S_b = loss_b * (M_b + 1e-2),  loss = sum_b S_b / (sum_b M_b + 1e-2),
+    grad = sum_b grad_b * (M_b + 1e-2) / (sum_b M_b + 1e-2); pred rows are the runs' own.  The recorded DropPath factors are stored in
+    the order a B = 8 forward consumes them (blocks 0..2 run on the concatenated [x ; y] batch: x-stream factors of all samples,
+    then y-stream factors).  tests/test_model_gpu.py checks the fp32 build against this at 1e-3 (which also pins the assembly
+    arithmetic) and the bf16 build at its stated tolerances."""
+    cfg = O.vit_large_config()
+    model, _ = build_reference(cfg, 1)
+    model.train()
+    imgs, tgts, mask, valid = O.synthetic_batch(cfg, batch, 4321, "random")
+    names = [n for n, _ in model.named_parameters()]
+    S, M, recs, preds = [], [], [], []
+    gsum = None
+    torch.manual_seed(11)
+    for b_ in range(batch):
+        rec = []
+        orig = _record_droppath(rec)
+        for p in model.parameters():
+            p.grad = None
+        v = valid[b_:b_ + 1].clone()
+        loss, pred, _ = model(imgs[b_:b_ + 1], tgts[b_:b_ + 1], bool_masked_pos=mask[b_:b_ + 1].reshape(1, *cfg.grid), valid=v)
+        loss.backward()
+        ref_import._DropPath.forward = orig
+        # sum(mask) of this sample: mask (0/1 per patch) x patch pixels x 3 channels x valid (ones here, no sample is ignored)
+        Mb = float(mask[b_].double().sum()) * cfg.patch_size ** 2 * 3
+        assert float(v.double().min()) == 1.0, "ignore rule fired: the assembly below assumes it does not"
+        S.append(loss.item() * (Mb + 1e-2))
+        M.append(Mb)
+        recs.append(rec)
+        preds.append(pred.detach().reshape(-1)[::PRED_STRIDE].clone())
+        g = [p.grad.detach().double() * (Mb + 1e-2) for p in model.parameters()]
+        gsum = g if gsum is None else [a + c for a, c in zip(gsum, g)]
+        print("  sample", b_, "loss", loss.item(), flush=True)
+    den = sum(M) + 1e-2
+    out[prefix + "loss"] = np.float64(sum(S) / den)
+    out[prefix + "pred_sample"] = torch.stack(preds).numpy()
+    out[prefix + "pred_stride"] = np.int64(PRED_STRIDE)
+    grad_digest([(n, (g / den).float()) for n, g in zip(names, gsum)], out, prefix)
+    # DropPath factors in B = 8 consumption order: per recorded call k (2 per block for blocks 1..23), concat over samples;
+    # calls with 2 factors per sample (blocks <= 2, the [x ; y] batch) become [x of all samples, y of all samples]
+    ncall = len(recs[0])
+    flat, lens = [], []
+    for k in range(ncall):
+        per = [recs[b_][k] for b_ in range(batch)]
+        if per[0].numel() == 2:
+            v = torch.cat([torch.stack([p_[0] for p_ in per]), torch.stack([p_[1] for p_ in per])])
+        else:
+            v = torch.cat(per)
+        flat.append(v)
+        lens.append(v.numel())
+    out[prefix + "drop_scales_flat"] = torch.cat(flat).numpy()
+    out[prefix + "drop_scales_len"] = np.array(lens)
+
+
+def case_seggpt_vit_large_n32(out, prefix, n_prompts=32):
+    """BASELINE configs[3]: seggpt_vit_large_patch16_input896x448, 32 in-context prompts sharing one query, feature ensemble from block 0
+    (merge_between_batch = 0), seg_type ones, bottom-half mask -- forward of the unmodified reference (models_seggpt.py:471-479)."""
+    cfg = O.vit_large_config(seggpt=True)
+    model, _ = build_reference(cfg, 2)
+    model.eval()
+    imgs, tgts, _, valid = O.synthetic_batch(cfg, n_prompts, 777, "half")
+    # one query under all prompts: the query half (rows 448..895) of imgs is the same picture for every prompt (seggpt_engine.py:75-90)
+    imgs[:, :, cfg.img_size[0] // 2:, :] = imgs[0:1, :, cfg.img_size[0] // 2:, :]
+    L = cfg.grid[0] * cfg.grid[1]
+    mask = torch.zeros(1, L)
+    mask[:, L // 2:] = 1
+    seg_type = torch.ones(n_prompts, 1)
+    with torch.no_grad():
+        loss, pred, _ = model(imgs, tgts, mask, valid, seg_type, 0)
+    out[prefix + "loss"] = np.float64(loss.item())
+    flat = pred.reshape(n_prompts, -1)
+    out[prefix + "pred_sample"] = flat[:, ::PRED_STRIDE].numpy()
+    out[prefix + "pred_stride"] = np.int64(PRED_STRIDE)
+    out[prefix + "pred_norm"] = flat.double().norm(dim=1).numpy()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also generate the ViT-L 896x448 fixture")
     ap.add_argument("--small", action="store_true", help="only (re)generate the small HIP-path fixture")
     ap.add_argument("--skip-tiny", action="store_true")
+    ap.add_argument("--vitl-b8", action="store_true", help="only: ViT-L B=8 train-mode fixture (8 B=1 runs of the reference, ~3 min, 15 GB)")
+    ap.add_argument("--seggpt-n32", action="store_true", help="only: SegGPT ViT-L N=32 feature-ensemble forward (~6 min)")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
+    if args.vitl_b8:
+        out = {}
+        case_vit_large_b8_train(out, "vitl_b8_train/")
+        np.savez_compressed(os.path.join(HERE, "painter_vitl_b8.npz"), **out)
+        print("painter_vitl_b8.npz loss", out["vitl_b8_train/loss"])
+        return
+    if args.seggpt_n32:
+        out = {}
+        case_seggpt_vit_large_n32(out, "seggpt_n32/")
+        np.savez_compressed(os.path.join(HERE, "seggpt_vitl_n32.npz"), **out)
+        print("seggpt_vitl_n32.npz loss", out["seggpt_n32/loss"])
+        return
 
     if args.skip_tiny or args.small:
         return _rest(args)

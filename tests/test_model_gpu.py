@@ -170,6 +170,90 @@ def test_vit_large_bf16_loss_and_pred_yardstick():
     G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-1, 5e-2, 1e-1)
 
 
+def _vitl_b8_case(dtype):
+    fx = G.load("painter_vitl_b8.npz")
+    case, cfg = "vitl_b8_train/", O.vit_large_config()
+    m, _ = build(cfg, 1, dtype, train=True)
+    flat = torch.from_numpy(fx[case + "drop_scales_flat"])
+    chunks = list(torch.split(flat, [int(x) for x in fx[case + "drop_scales_len"]]))
+    assert len(chunks) == 2 * (cfg.depth - 1) and chunks[0].numel() == 16 and chunks[-1].numel() == 8
+    m._drop_override = [(None, None)] + [(chunks[2 * i].cuda().contiguous(), chunks[2 * i + 1].cuda().contiguous()) for i in range(cfg.depth - 1)]
+    loss, pred, _, _ = run_painter(m, cfg, 8, 4321, "random")
+    stride = int(fx[case + "pred_stride"])
+    ps = pred.reshape(8, -1)[:, ::stride].cpu()
+    return fx, case, m, loss, ps
+
+
+def test_vit_large_b8_train_fp32_vs_reference_golden():
+    """BASELINE configs[1] at its real batch (B = 8), TRAIN mode with the reference's recorded DropPath factors, exact-fp32 build:
+    loss, every sample's pred, every parameter gradient against the fixture assembled from eight B = 1 runs of the unmodified
+    reference (tests/golden/make_golden.py::case_vit_large_b8_train) -- also pins that assembly."""
+    fx, case, m, loss, ps = _vitl_b8_case("fp32")
+    ref_loss = float(fx[case + "loss"])
+    assert abs(loss.item() - ref_loss) < 1e-4 * abs(ref_loss), (loss.item(), ref_loss)
+    for b_ in range(8):
+        assert G.rel_err(ps[b_], fx[case + "pred_sample"][b_]) < 1e-3, b_
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-3, 1e-3, 1e-3)
+
+
+def test_vit_large_b8_train_bf16_vs_reference_golden():
+    """The timed configuration itself (bf16 operands, B = 8, train mode, the kernels bench.py runs) against the reference fixture.
+    Tolerances: loss 2e-3; pred relative Frobenius 3e-2 per sample (the reference's own bf16-autocast deviation is 1e-2,
+    BASELINE.md section 4); gradient digests at the bf16 model-level bound."""
+    fx, case, m, loss, ps = _vitl_b8_case("bf16")
+    ref_loss = float(fx[case + "loss"])
+    assert abs(loss.item() - ref_loss) < 2e-3 * abs(ref_loss), (loss.item(), ref_loss)
+    worst = max(G.rel_fro(ps[b_], fx[case + "pred_sample"][b_]) for b_ in range(8))
+    assert worst < 3e-2, worst
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-1, 5e-2, 1e-1)
+
+
+def test_seggpt_vit_large_n32_ensemble_and_hipgraph_vs_reference_golden():
+    """BASELINE configs[3]: seggpt_vit_large_patch16_input896x448, 32 prompts over one query, feature ensemble from block 0, bf16,
+    forward: eager against the unmodified reference's output (fixture), then captured in a hipGraph and replayed -- the replay must
+    be bit-identical to the eager run (same kernels, no host sync inside the forward)."""
+    fx = G.load("seggpt_vitl_n32.npz")
+    case, cfg, N = "seggpt_n32/", O.vit_large_config(seggpt=True), 32
+    m, _ = build(cfg, 2, "bf16")
+    imgs, tgts, _, valid = O.synthetic_batch(cfg, N, 777, "half")
+    imgs[:, :, cfg.img_size[0] // 2:, :] = imgs[0:1, :, cfg.img_size[0] // 2:, :]
+    L = cfg.grid[0] * cfg.grid[1]
+    mask = torch.zeros(1, L)
+    mask[:, L // 2:] = 1
+    imgs, tgts, valid, mask, seg_type = imgs.cuda(), tgts.cuda(), valid.cuda(), mask.cuda(), torch.ones(N, 1).cuda()
+
+    def fwd():
+        with torch.no_grad():
+            return m(imgs, tgts, mask, valid, seg_type, 0)
+
+    loss, pred, mo = fwd()
+    torch.cuda.synchronize()
+    ref_loss = float(fx[case + "loss"])
+    assert abs(loss.item() - ref_loss) < 3e-3 * abs(ref_loss), (loss.item(), ref_loss)
+    stride = int(fx[case + "pred_stride"])
+    ps = pred.reshape(N, -1)[:, ::stride].float().cpu()
+    worst = max(G.rel_fro(ps[i], fx[case + "pred_sample"][i]) for i in range(N))
+    assert worst < 3e-2, worst
+    norms = pred.reshape(N, -1).double().norm(dim=1).cpu().numpy()
+    assert np.abs(norms / fx[case + "pred_norm"] - 1).max() < 1e-2
+    assert mo.shape == (1, L) and mo.dtype == torch.bool
+    eager_pred, eager_loss = pred.clone(), loss.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):          # warm-up on the capture stream (per-stream workspaces)
+        fwd()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        g_loss, g_pred, _ = fwd()
+    g_pred.zero_()
+    graph.replay()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(g_pred, eager_pred) and torch.equal(g_loss, eager_loss)
+
+
 def test_ddp_gradient_path_single_rank_rccl():
     """The multi-GPU gradient exchange exercised on one GPU (tools/ddp_selftest.py): 1-rank RCCL group, GradSync driven from the
     two-stream backward; gradients must be bit-identical to the run without the exchange (this caught a cross-stream allocator
