@@ -86,6 +86,9 @@ int64_t pa_attn_tables_bytes(int dtype, int batch, int L, int heads, int Hp, int
 /* 0 = default kernels for the grid (generation 3, 4-wave build, where it applies), 3 = the same explicitly, 4 = generation 3 in
  * its paired 8-wave build, 2 = never use the 28-token-wide generation-3 kernels (diagnostics, A/B, cross-generation tests) */
 int pa_attn_set_generation(int generation);
+/* diagnostics: enable != 0 runs the generation-3 dQ kernel with s_memtime stamps (two workgroups, waves 0 / 1, 64 tiles, 8 slots);
+ * host_out (may be NULL) receives the 2 x 2 x 64 x 8 stamps of the last traced launch */
+int pa_attn_trace(int enable, unsigned long long* host_out);
 int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse,
                 void* tables, int batch, int L, int heads, int Hp, int Wp, float scale, hipStream_t stream);
 

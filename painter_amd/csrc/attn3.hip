@@ -183,7 +183,9 @@ __global__ __launch_bounds__(NT, STAGES == 1 ? 4 : 2) void fwd_kernel(const bf16
 // =============================================================================================== backward: dQ, bias gradients
 // LDS: [K img | V img] x 2 | thT 4 waves x [Hp][32 q] bf16 (values, replaced row by row by their gradients) | 7 one-hot images
 // NDL = true keeps -Delta in 16 accumulator-init registers (dP - Delta comes out of the MFMA chain); false adds it on the VALU
-template <int MINW, bool NDL>
+// diagnostics (pa_attn_trace): s_memtime stamps of two workgroups' waves 0 / 1 at seven points of every tile iteration
+__device__ unsigned long long g_trace[2 * 2 * 64 * 8];
+template <int MINW, bool NDL, bool TR = false>
 __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcatT,
                                                           const bf16* __restrict__ dout, size_t lddo, const float* __restrict__ lse,
                                                           const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv,
@@ -243,9 +245,19 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     eacc = zero16();
     unsigned char* thw = thT + ql * 2;
 
+    const int trwg = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : -1);
     auto body = [&](auto pc, int a) {
         constexpr int P = decltype(pc)::value;
         const int j = a * PH + P;
+        auto mark = [&](int pt) {
+            if constexpr (TR) {
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned long long t = __builtin_amdgcn_s_memtime();
+                if (trwg >= 0 && wave < 2 && lane == 0 && j < 64) g_trace[((trwg * 2 + wave) * 64 + j) * 8 + pt] = t;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        mark(0);
         if (j + 1 < ntile) {
             ks.load(kbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
             vs.load(vbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
@@ -263,6 +275,8 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
 #pragma unroll
             for (int s = 0; s < 4; ++s) { vfr[s] = rowfrag(vimg, la, s); kfr[s] = rowfrag(kimg, la, s); }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TR) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+            mark(1);
             f32x16 sacc = zero16(), dpacc;
             sacc = mfma(ef0, as_frag(T0), sacc);
             dpacc = mfma(vfr[0], dof[0], ndl);
@@ -278,6 +292,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             etr[0] = etrfrag(ei, ea, 0);
             etr[1] = etrfrag(ei, ea, 1);
             __builtin_amdgcn_sched_barrier(0);
+            mark(2);
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -285,6 +300,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
                 ds[r] = NDL ? pr * dpacc[r] : pr * (dpacc[r] + ndlt);
             }
             const bf16x8 dsf0 = packfrag(ds), dsf1 = packfrag(ds + 8);
+            mark(3);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 dq[db] = mfma(ktr[db][0], dsf0, dq[db]);
@@ -302,11 +318,14 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
                 }
             }
         }
+        mark(4);
         if (j + 1 < ntile) {
             ks.store(smem + ((j + 1) & 1) * STAGE_QK, tid);
             vs.store(smem + ((j + 1) & 1) * STAGE_QK + IMG, tid);
         }
+        mark(5);
         __syncthreads();
+        mark(6);
     };
     for (int a = 0; a < Hp / RPP; ++a) {
         body(std::integral_constant<int, 0>{}, a);
@@ -334,7 +353,12 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         // (the table gradients are plain sums of dS over the keys of a kw / kh class = d loss / d G: the bias enters the logit with
         // coefficient 1, the 1 / scale inside T and the scale inside `sl` cancel)
         bf16* dgrow = dG + ((size_t)(b * L + q) * H + h) * NRP;
+        // the Rcat^T fragments of step s+1 are requested before the gather of step s (the loop is latency-bound otherwise: one L2 round
+        // trip per step, ~1/4 of a workgroup's life at the ViT-L grid)
+        bf16x8 rf[2] = {gfrag(rcatT + (size_t)ql * NRP, 0, g), gfrag(rcatT + (size_t)(32 + ql) * NRP, 0, g)};
         for (int s = 0; s < NRP / 16; ++s) {
+            const int sn = min(s + 1, NRP / 16 - 1);
+            const bf16x8 rn[2] = {gfrag(rcatT + (size_t)ql * NRP, sn, g), gfrag(rcatT + (size_t)(32 + ql) * NRP, sn, g)};
             float gv[8];
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
@@ -353,8 +377,10 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             const bf16x8 gf = packfrag(gv);
             *reinterpret_cast<uint4*>(dgrow + 16 * s + 8 * g) = __builtin_bit_cast(uint4, gf);
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
-                dq[db] = mfma(gfrag(rcatT + (size_t)(db * 32 + ql) * NRP, s, g), gf, dq[db]);
+            for (int db = 0; db < 2; ++db) {
+                dq[db] = mfma(rf[db], gf, dq[db]);
+                rf[db] = rn[db];
+            }
         }
         stage_rows(stg, dq, 1.f, lane);
         write_rows(stg, dqkv + (size_t)(b * L + qt * 32) * ldq + h * ATT_HD, ldq, lane);
@@ -556,8 +582,19 @@ static bool attn3_paired() {
     return g_attn_generation == 4 || (on && g_attn_generation != 3);
 }
 extern "C" int pa_attn_set_generation(int generation) {
-    if (generation != 0 && generation != 2 && generation != 3 && generation != 4) return (int)hipErrorInvalidValue;
+    if (generation != 0 && (generation < 2 || generation > 5)) return (int)hipErrorInvalidValue;
     g_attn_generation = generation;
+    return 0;
+}
+static int g_attn_trace = 0;
+// PA_ATTN3_PIPE=1 / pa_attn_set_generation(5): software-pipelined backward (attn3s.hip)
+static bool attn3_pipelined() {
+    static const int on = [] { const char* e = getenv("PA_ATTN3_PIPE"); return e ? atoi(e) : 0; }();
+    return g_attn_generation == 5 || (on && g_attn_generation == 0);
+}
+extern "C" int pa_attn_trace(int enable, unsigned long long* host_out) {
+    g_attn_trace = enable;
+    if (host_out != nullptr) return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(a3::g_trace), sizeof(a3::g_trace));
     return 0;
 }
 bool attn3_ok(int L, int Hp, int Wp) {
@@ -606,11 +643,13 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
     // PA_ATTN3_DQ_WAVES / PA_ATTN3_DKV_WAVES: waves per SIMD the register allocation aims at (2 or 3)
     static const int dq_w = [] { const char* v = getenv("PA_ATTN3_DQ_WAVES"); return v ? atoi(v) : 2; }();
     static const int dkv_w = [] { const char* v = getenv("PA_ATTN3_DKV_WAVES"); return v ? atoi(v) : 2; }();
-    {
+    if (attn3_pipelined() && !g_attn_trace) {
+        if ((e = attn3s_dq(qkv, ldq, rcatT, dout, lddo, lse, tables, dqkv, dG, Bn, L, H, Hp, Wp, scale, st))) return e;
+    } else {
         const size_t smem = 2 * (size_t)STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG;
-        auto kern = dq_w == 3 ? bwd_dq_kernel<3, false> : bwd_dq_kernel<2, true>;
-        static bool done2 = false, done3 = false;
-        if ((e = set_smem(reinterpret_cast<const void*>(kern), dq_w == 3 ? done3 : done2))) return e;
+        auto kern = g_attn_trace ? bwd_dq_kernel<2, true, true> : (dq_w == 3 ? bwd_dq_kernel<3, false> : bwd_dq_kernel<2, true>);
+        static bool done2 = false, done3 = false, donet = false;
+        if ((e = set_smem(reinterpret_cast<const void*>(kern), g_attn_trace ? donet : (dq_w == 3 ? done3 : done2)))) return e;
         PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcatT, dout, (size_t)lddo, lse, tb, dqkv, dG, L, H, Hp,
                   NRP, scale, nblk, a3_xcd_map_on());
         if ((e = (int)hipGetLastError())) return e;

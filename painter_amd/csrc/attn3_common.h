@@ -23,7 +23,7 @@ DEVI void build_eimg(unsigned char* eimg, int tid, int nthreads = NT) {
     for (int idx = tid; idx < PH * 512; idx += nthreads) {
         const int ph = idx >> 9, i = (idx >> 4) & 31, dw = idx & 15;
         const int c = dw >> 2, s = c >> 1, g = c & 1;
-        const int a = 4 * ph + i, kw = a % WP, khr = ph + (a >= WP ? 1 : 0);
+        const int a = 4 * ph + i, kw = a >= WP ? a - WP : a, khr = ph + (a >= WP ? 1 : 0);        // a < 2 * WP
         uint32_t w = 0;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {

@@ -377,7 +377,12 @@ __global__ __launch_bounds__(NTP, 2) void bwd_dq_kernel(const bf16* __restrict__
         for (int r = 0; r < 16; ++r) { dq[0][r] *= scale; dq[1][r] *= scale; }
         // r-space: dG[q][r] gathers the tables; dQ^T[d][q] += sum_r Rcat[r][d] dG[q][r]; dG is also the operand of d rel_pos
         bf16* dgrow = dG + ((size_t)(b * L + q) * H + h) * NRP;
+        // the Rcat^T fragments of step s+1 are requested before the gather of step s (the loop is latency-bound otherwise: one L2 round
+        // trip per step, ~1/4 of a workgroup's life at the ViT-L grid)
+        bf16x8 rf[2] = {gfrag(rcatT + (size_t)ql * NRP, 0, g), gfrag(rcatT + (size_t)(32 + ql) * NRP, 0, g)};
         for (int s = 0; s < NRP / 16; ++s) {
+            const int sn = min(s + 1, NRP / 16 - 1);
+            const bf16x8 rn[2] = {gfrag(rcatT + (size_t)ql * NRP, sn, g), gfrag(rcatT + (size_t)(32 + ql) * NRP, sn, g)};
             float gv[8];
 #pragma unroll
             for (int t8 = 0; t8 < 8; ++t8) {
@@ -396,8 +401,10 @@ __global__ __launch_bounds__(NTP, 2) void bwd_dq_kernel(const bf16* __restrict__
             const bf16x8 gf = packfrag(gv);
             *reinterpret_cast<uint4*>(dgrow + 16 * s + 8 * g) = __builtin_bit_cast(uint4, gf);
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
-                dq[db] = mfma(gfrag(rcatT + (size_t)(db * 32 + ql) * NRP, s, g), gf, dq[db]);
+            for (int db = 0; db < 2; ++db) {
+                dq[db] = mfma(rf[db], gf, dq[db]);
+                rf[db] = rn[db];
+            }
         }
         stage_rows(mine, dq, 1.f, lane);                    // same-wave LDS ops are ordered: the gather above is complete
         write_rows(mine, dqkv + (size_t)(b * L + qt * 32) * ldq + h * ATT_HD, ldq, lane);

@@ -59,7 +59,7 @@ def main():
         ref, lse_ref = attn_reference(q64, rh64, rw64, B, L, H, Hp, Wp, 0.125)
         ref.backward(dout.double())
         D = H * 64
-        for gen_ in (2, 4, 0):
+        for gen_ in (2, 0, 5):
             lib.pa_attn_set_generation(gen_)
             out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
             dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables)
@@ -67,7 +67,7 @@ def main():
             errs = dict(out=rel(out, ref.detach()), lse=rel(lse, lse_ref.detach()), dq=rel(dqkv[:, :D], q64.grad[:, :D]),
                         dk=rel(dqkv[:, D:2 * D], q64.grad[:, D:2 * D]), dv=rel(dqkv[:, 2 * D:], q64.grad[:, 2 * D:]),
                         drh=rel(drcat[:nh], rh64.grad), drw=rel(drcat[nh:nh + nw], rw64.grad))
-            print("shape", (B, H, Hp, Wp), "gen", {0: "3 4-wave", 4: "3 paired", 2: "2"}[gen_], {k: "%.2e" % v for k, v in errs.items()}, flush=True)
+            print("shape", (B, H, Hp, Wp), "gen", {0: "3 4-wave", 5: "3 pipelined dq", 4: "3 paired", 2: "2"}[gen_], {k: "%.2e" % v for k, v in errs.items()}, flush=True)
             if gen_ != 2 and max(errs.values()) > 3e-2:
                 torch.set_printoptions(precision=2, linewidth=250)
                 print("  out tiles ", tile_err(out, ref.detach(), B * L)[:64])

@@ -1,0 +1,51 @@
+"""Ablation of the software-pipelined dQ kernel (attn3s.hip, PA_ATTN3_ABL bit mask; results are wrong with any bit set, only the time
+matters): which ingredient of a tile iteration costs what.  Times the dQ + dKV pair; dKV is constant, so differences are dQ's."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from painter_amd import ops            # noqa: E402
+from painter_amd._lib import lib       # noqa: E402
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    B, H, Hp, Wp = 8, 16, 56, 28
+    L = Hp * Wp
+    g = torch.Generator().manual_seed(0)
+    T = torch.bfloat16
+    qkv = torch.randn(B * L, 3 * H * 64, generator=g).to(T).cuda()
+    dout = torch.randn(B * L, H * 64, generator=g).to(T).cuda()
+    rel_h = (torch.randn(2 * Hp - 1, 64, generator=g) * 0.05).cuda()
+    rel_w = (torch.randn(2 * Wp - 1, 64, generator=g) * 0.05).cuda()
+    rcat = ops.relpos_pack(rel_h, rel_w, Hp, Wp, T)
+    rcatT = ops.relpos_pack_t(rel_h, rel_w, Hp, Wp, T)
+    lib.pa_attn_set_generation(5)
+    out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
+    names = {1: "no staging", 2: "no barrier", 4: "no LDS frag loads", 8: "no exp", 16: "no write-back", 32: "no MFMA group 2", 64: "no MFMA group 1"}
+    masks = [0, 1, 3, 4, 7, 8, 16, 32, 64, 96, 96 + 8, 127, 0]
+    for _ in range(2):
+        for m in masks:
+            os.environ["PA_ATTN3_ABL"] = str(m)
+            t = timeit(lambda: ops.attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables))
+            print("abl %3d  dq+dkv %.3f ms   [%s]" % (m, t, ", ".join(v for k, v in names.items() if m & k) or "full kernel"), flush=True)
+    os.environ.pop("PA_ATTN3_ABL")
+    lib.pa_attn_set_generation(0)
+
+
+if __name__ == "__main__":
+    main()

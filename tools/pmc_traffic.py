@@ -9,7 +9,8 @@ import glob
 import json
 import sys
 
-KERNELS = {"fc1": "Epi4BiasGelu", "attn_fwd": "a2::fwd_kernel", "wgrad": "Epi4Slab"}
+KERNELS = {"fc1": "Epi4BiasGelu", "attn_fwd": "a3::fwd_kernel", "wgrad": "Epi4Slab", "dgrad": "gemm256_kernelILb0ELb1E8Epi4Bias",
+           "attn_bwd_dq": "a3::bwd_dq_kernel", "attn_bwd_dkv": "a3::bwd_dkv_kernel"}
 
 
 def per_launch(path, counter):

@@ -122,6 +122,38 @@ __global__ void k_barrier(uint64_t* out, int iters) {
     stamp(out, t0, 0);
 }
 
+// Packed-fp32 check: every lane evaluates the same recurrence twice -- with v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+// (inline asm, op_sel broadcast forms as hipcc's SLP vectoriser emits them) and with scalar v_fma_f32 / v_mul_f32 / v_add_f32 -- and
+// counts bit differences.  Run alone and beside an MFMA kernel on a second stream.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__global__ void k_pkcheck(unsigned* bad, int iters) {
+    const float s0 = 1.0f + (threadIdx.x & 63) * 0.001f + blockIdx.x * 1e-5f;
+    f32x2 a = {s0, s0 * 0.5f}, acc = {0.f, 0.f};
+    float a0 = s0, a1 = s0 * 0.5f, c0 = 0.f, c1 = 0.f;
+    const float mu = 0.37f, rs = 1.0003f;
+    unsigned nbad = 0;
+    for (int it = 0; it < iters; ++it) {
+        f32x2 t, u;
+        const f32x2 murs = {mu, rs};
+        // t = (a - mu) * rs  with mu, rs broadcast from one register pair (op_sel), acc += t * a ; a = t * 0.999 + 0.001
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(murs));
+        asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(u) : "v"(murs), "v"(t));
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(u), "v"(a));
+        const f32x2 k9 = {0.999f, 0.999f}, k1 = {0.001f, 0.001f};
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(a) : "v"(u), "v"(k9), "v"(k1));
+        const float t0 = (a0 - mu) * rs, t1 = (a1 - mu) * rs;
+        c0 = __builtin_fmaf(t0, a0, c0);
+        c1 = __builtin_fmaf(t1, a1, c1);
+        a0 = __builtin_fmaf(t0, 0.999f, 0.001f);
+        a1 = __builtin_fmaf(t1, 0.999f, 0.001f);
+        if ((it & 63) == 63) {
+            nbad += (__builtin_bit_cast(unsigned, acc[0]) != __builtin_bit_cast(unsigned, c0)) + (__builtin_bit_cast(unsigned, acc[1]) != __builtin_bit_cast(unsigned, c1));
+            nbad += (__builtin_bit_cast(unsigned, a[0]) != __builtin_bit_cast(unsigned, a0)) + (__builtin_bit_cast(unsigned, a[1]) != __builtin_bit_cast(unsigned, a1));
+        }
+    }
+    if (nbad) atomicAdd(bad, nbad);
+}
+
 static uint64_t* d_out;
 static float* d_sink;
 template <class F> static void run(const char* name, int block, double per, F launch) {
@@ -169,5 +201,25 @@ int main() {
     run("phased M|V barriers, 4 chains, NF=0 (cycles per tile)", 512, IT * 1.0, L((k_phased<0, 4>), 512, d_out, d_sink, IT));
     run("s_barrier only, 8 waves (cycles per barrier)", 512, IT * 1.0, L(k_barrier, 512, d_out, IT));
     run("s_barrier only, 4 waves (cycles per barrier)", 256, IT * 1.0, L(k_barrier, 256, d_out, IT));
+    {   // packed-fp32 arithmetic alone, and beside MFMA workgroups of another kernel (second stream)
+        unsigned* d_bad;
+        hipMalloc(&d_bad, 4);
+        hipStream_t s1, s2;
+        hipStreamCreate(&s1);
+        hipStreamCreate(&s2);
+        for (int mode = 0; mode < 2; ++mode) {
+            hipMemset(d_bad, 0, 4);
+            hipDeviceSynchronize();
+            for (int rep = 0; rep < 40; ++rep) {
+                if (mode) hipLaunchKernelGGL(k_mfma<4>, dim3(192), dim3(512), 0, s2, d_out, d_sink, 3000);
+                for (int k = 0; k < 8; ++k) hipLaunchKernelGGL(k_pkcheck, dim3(1024), dim3(256), 0, s1, d_bad, 4096);
+            }
+            hipDeviceSynchronize();
+            unsigned h = 0;
+            hipMemcpy(&h, d_bad, 4, hipMemcpyDeviceToHost);
+            printf("packed-fp32 vs scalar fp32 recurrence, %s: %u bit mismatches in 320 launches x 262144 lanes x 64 checks\n",
+                   mode ? "beside an MFMA kernel on a second stream" : "alone", h);
+        }
+    }
     return 0;
 }
