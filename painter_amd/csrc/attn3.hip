@@ -193,6 +193,16 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
                                                           int xcd_map) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, ql = lane & 31;
+    const int trwg = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : -1);
+    auto coarse = [&](int pt) {          // traced build: stamps 60 kernel start, 61 loop start, 62 loop end, 63 kernel end (slot 0 of each)
+        if constexpr (TR) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (trwg >= 0 && wave < 2 && lane == 0) g_trace[((trwg * 2 + wave) * 64 + pt) * 8] = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    coarse(60);
     int blk, bh;
     wg_coords(nblk, xcd_map, blk, bh);
     const int b = bh / H, h = bh % H, D = H * ATT_HD;
@@ -245,7 +255,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     eacc = zero16();
     unsigned char* thw = thT + ql * 2;
 
-    const int trwg = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : -1);
+    coarse(61);
     auto body = [&](auto pc, int a) {
         constexpr int P = decltype(pc)::value;
         const int j = a * PH + P;
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             if constexpr (TR) {
                 __builtin_amdgcn_sched_barrier(0);
                 const unsigned long long t = __builtin_amdgcn_s_memtime();
-                if (trwg >= 0 && wave < 2 && lane == 0 && j < 64) g_trace[((trwg * 2 + wave) * 64 + j) * 8 + pt] = t;
+                if (trwg >= 0 && wave < 2 && lane == 0 && j < 60) g_trace[((trwg * 2 + wave) * 64 + j) * 8 + pt] = t;
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -336,6 +346,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         body(std::integral_constant<int, 5>{}, a);
         body(std::integral_constant<int, 6>{}, a);
     }
+    coarse(62);
     // every wave is past its last read of the K/V stages and the one-hot images (the loop ends with a barrier): the image region
     // becomes the fp32 kw-gradient table [wave][32 q][28], the K/V region the per-wave dQ staging tiles
     float* twg = reinterpret_cast<float*>(eimg + wave * (32 * WP * 4));
@@ -385,6 +396,8 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         stage_rows(stg, dq, 1.f, lane);
         write_rows(stg, dqkv + (size_t)(b * L + qt * 32) * ldq + h * ATT_HD, ldq, lane);
     }
+    if constexpr (TR) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    coarse(63);
 }
 
 // =============================================================================================== backward: dK, dV

@@ -11,6 +11,7 @@ reference's transform stack (main_train.py:232-251) did in the worker.  tests/te
 import json
 import os.path
 import random
+import time
 
 import numpy as np
 import torch
@@ -29,19 +30,18 @@ class PairSpecDataset(torch.utils.data.Dataset):
     def __init__(self, root, json_path_list, masked_position_generator=None, use_two_pairs=True, half_mask_ratio=0.,
                  input_size=(896, 448), min_random_scale=0.3, train=True, jitter=(0.4, 0.4, 0.2, 0.1), jitter_p=0.8, flip_p=0.5):
         self.root = root
-        self.pairs = []
-        self.weights = []
-        for idx, json_path in enumerate(json_path_list):
-            cur_pairs = json.load(open(json_path))
-            self.pairs.extend(cur_pairs)
-            cur_num = len(cur_pairs)
-            self.weights.extend([TYPE_WEIGHTS[idx] * 1. / cur_num] * cur_num)
+        self.pairs, self.weights = [], []
+        for list_index, path in enumerate(json_path_list):           # one json list per task; each list shares its task weight evenly
+            with open(path) as f:
+                entries = json.load(f)
+            self.pairs += entries
+            self.weights += [TYPE_WEIGHTS[list_index] / len(entries)] * len(entries)
         self.use_two_pairs = use_two_pairs
-        if self.use_two_pairs:
+        if use_two_pairs:                                             # partner candidates: indices of the pairs of each type (:66-73)
             self.pair_type_dict = {}
-            for idx, pair in enumerate(self.pairs):
-                if "type" in pair:
-                    self.pair_type_dict.setdefault(pair["type"], []).append(idx)
+            for index, entry in enumerate(self.pairs):
+                if "type" in entry:
+                    self.pair_type_dict.setdefault(entry["type"], []).append(index)
         self.masked_position_generator = masked_position_generator
         self.half_mask_ratio = half_mask_ratio
         self.input_size = tuple(input_size)
@@ -50,21 +50,20 @@ class PairSpecDataset(torch.utils.data.Dataset):
         self.jitter, self.jitter_p, self.flip_p = tuple(jitter), jitter_p, flip_p
 
     def _load_image(self, path):
-        """pairdataset.py:81-98 (the retry loop on OSError included)."""
-        while True:
+        """What pairdataset.py:81-98 hands to the transforms: the file as an RGB PIL picture.  A file that cannot be opened is
+        retried once a second for ever (a flaky network mount stalls the worker, it does not kill the epoch); nyuv2 depth maps
+        (16-bit, 1e-4 m units, 10 m range) are rescaled to 0..255 floats before the RGB conversion."""
+        full = os.path.join(self.root, path)
+        picture = None
+        while picture is None:
             try:
-                img = Image.open(os.path.join(self.root, path))
-            except OSError as e:
-                print(f"Catched exception: {str(e)}. Re-trying...")
-                import time
+                picture = Image.open(full)
+            except OSError as err:
+                print("could not open %s (%s), trying again in 1 s" % (full, err))
                 time.sleep(1)
-            else:
-                break
-        if "sync_depth" in path:                        # nyuv2 depth: 0..10 m in 1e-4 m units -> 0..255
-            img = np.array(img) / 10000.
-            img = img * 255
-            img = Image.fromarray(img)
-        return img.convert("RGB")
+        if "sync_depth" in path:
+            picture = Image.fromarray(np.array(picture) / 10000. * 255)
+        return picture.convert("RGB")
 
     def _pair_spec(self, pair, stack):
         """One call of `cur_transforms(image, target, ...)` (pairdataset.py:135, :144): the draws of the chosen stack, in its order."""

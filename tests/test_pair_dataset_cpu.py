@@ -132,3 +132,22 @@ def test_collate_specs(dataset_files):
     loader = torch.utils.data.DataLoader(ds, batch_size=4, collate_fn=PD.collate_specs, num_workers=0)
     specs, masks = next(iter(loader))
     assert len(specs) == 4 and isinstance(specs[0], PP.SampleSpec) and tuple(masks.shape) == (4, 56, 28) and int(masks[0].sum()) == 784
+
+
+def test_load_image_depth_rescale_and_plain_files(dataset_files, tmp_path):
+    """`_load_image` beside the reference's (pairdataset.py:81-98): a 16-bit nyuv2 `sync_depth` map (1e-4 m units) and a plain RGB file."""
+    root, lists = dataset_files
+    ref_mod = ref_import.load_reference_pairdataset()
+    depth = (np.random.RandomState(3).rand(37, 53) * 65535).astype(np.uint16)
+    depth[:4] = 0
+    depth[4:8] = 10000                                           # 1 m -> 255 after the rescale, everything above saturates in convert("RGB")
+    Image.fromarray(depth).save(tmp_path / "sync_depth_00001.png")
+    Image.fromarray(picture(77, 37, 53)).save(tmp_path / "rgb_00001.png")
+    sub = tmp_path / "list.json"
+    sub.write_text(json.dumps([{"image_path": "rgb_00001.png", "target_path": "sync_depth_00001.png", "type": "nyuv2_image2depth"}]))
+    ref = ref_mod.PairDataset(str(tmp_path), [str(sub)], transform=StandInStack("plain"), use_two_pairs=False)
+    ours = PD.PairSpecDataset(str(tmp_path), [str(sub)], use_two_pairs=False)
+    for name in ("sync_depth_00001.png", "rgb_00001.png"):
+        a, b = ref._load_image(name), ours._load_image(name)
+        assert a.mode == b.mode == "RGB" and np.array_equal(np.array(a), np.array(b))
+    assert len(np.unique(np.array(ours._load_image("sync_depth_00001.png")))) > 20

@@ -43,6 +43,9 @@ def main():
             it = t[1:, 0] - t[:-1, 0]
             print("wg %d wave %d  " % (wg, wv) + "  ".join("%s %6.0f" % (n, v) for n, v in zip(names[:6], d.mean(0))) + "   iteration %6.0f (min %d max %d)"
                   % (it.mean(), it.min(), it.max()))
+    for wg in range(2):
+        c = tr[wg, 0, 60:64, 0]
+        print("wg %d wave 0 coarse: prologue %d  loop %d  epilogue %d  cycles (kernel start -> end %d)" % (wg, c[1] - c[0], c[2] - c[1], c[3] - c[2], c[3] - c[0]))
     print("first iterations of wg 1 wave 0:", (tr[1, 0, 1:9, 0] - tr[1, 0, 0:8, 0]).tolist())
 
 
