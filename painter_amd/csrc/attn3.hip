@@ -224,13 +224,14 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     Stager ks, vs;
     ks.load(kbase, ldq, tid);
     vs.load(vbase, ldq, tid);
-    build_eimg(eimg, tid);
 
+    // every global load of the prologue is in flight before the LDS work (one-hot images, table copy) starts
     bf16x8 qf[4], dof[4];
     uint4 T0 = zero4(), T1 = zero4();
+    uint4 tch[4] = {zero4(), zero4(), zero4(), zero4()};          // this lane's chunks of the kh table (Hp * 4 chunks of 16 B per wave)
     float nlse2 = 0.f, ndlt = 0.f;
+    const unsigned char* tt = tables + ((size_t)bh * ntile + qt) * ttile_bytes(Hp);
     if (valid) {
-        const unsigned char* tt = tables + ((size_t)bh * ntile + qt) * ttile_bytes(Hp);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             qf[s] = gfrag(base + (size_t)q * ldq, s, g);
@@ -238,9 +239,18 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         }
         T0 = *reinterpret_cast<const uint4*>(tt + ql * 64 + 16 * g);
         T1 = *reinterpret_cast<const uint4*>(tt + ql * 64 + 32 + 16 * g);
-        for (int c = lane; c < Hp * 4; c += 64) *reinterpret_cast<uint4*>(thT + c * 16) = *reinterpret_cast<const uint4*>(tt + 2048 + c * 16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (lane + 64 * i < Hp * 4) tch[i] = *reinterpret_cast<const uint4*>(tt + 2048 + (lane + 64 * i) * 16);
         nlse2 = -lse[(size_t)bh * L + q] * LOG2E_F;
         ndlt = *reinterpret_cast<const float*>(tt + 2048 + (Hp + 2) * 64 + ql * 4);
+    }
+    build_eimg(eimg, tid);
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (lane + 64 * i < Hp * 4) *reinterpret_cast<uint4*>(thT + (lane + 64 * i) * 16) = tch[i];
+        for (int c = lane + 256; c < Hp * 4; c += 64) *reinterpret_cast<uint4*>(thT + c * 16) = *reinterpret_cast<const uint4*>(tt + 2048 + c * 16);
     }
     f32x16 ndl;
 #pragma unroll
@@ -366,32 +376,52 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         bf16* dgrow = dG + ((size_t)(b * L + q) * H + h) * NRP;
         // the Rcat^T fragments of step s+1 are requested before the gather of step s (the loop is latency-bound otherwise: one L2 round
         // trip per step, ~1/4 of a workgroup's life at the ViT-L grid)
-        bf16x8 rf[2] = {gfrag(rcatT + (size_t)ql * NRP, 0, g), gfrag(rcatT + (size_t)(32 + ql) * NRP, 0, g)};
-        for (int s = 0; s < NRP / 16; ++s) {
-            const int sn = min(s + 1, NRP / 16 - 1);
-            const bf16x8 rn[2] = {gfrag(rcatT + (size_t)ql * NRP, sn, g), gfrag(rcatT + (size_t)(32 + ql) * NRP, sn, g)};
-            float gv[8];
+        // The gather is branch-free (clamped addresses, selects) and one step ahead of its use, like the fragment loads: with a branch per
+        // element the eleven steps cost ~2000 cycles each (coarse stamps: 22k of a workgroup's 150k cycles sat in this loop).
+        const int nkh = 2 * Hp - 1;
+        auto gather = [&](int s, float (&gv)[8]) {
+            const int r0 = 16 * s + 8 * g;
+            if (r0 + 7 < nkh) {                              // kh entries only (wave-uniform up to the half-wave split: both tests below are per half)
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const int r = 16 * s + 8 * g + t;
-                float v = 0.f;
-                if (r < 2 * Hp - 1) {
-                    const int khh = qh + Hp - 1 - r;
-                    if (khh >= 0 && khh < Hp) v = (float)*reinterpret_cast<const bf16*>(thT + khh * 64 + ql * 2);
-                } else {
-                    const int rr = r - (2 * Hp - 1);
-                    const int kww = qw + WP - 1 - rr;
-                    if (rr < 2 * WP - 1 && kww >= 0 && kww < WP) v = twg[ql * WP + kww];
+                for (int t = 0; t < 8; ++t) {
+                    const int khh = qh + Hp - 1 - (r0 + t);
+                    const bool ok = khh >= 0 && khh < Hp;
+                    const float v = (float)*reinterpret_cast<const bf16*>(thT + (ok ? khh : 0) * 64 + ql * 2);
+                    gv[t] = ok ? v : 0.f;
                 }
-                gv[t] = v;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int r = r0 + t;
+                    const int khh = qh + Hp - 1 - r;
+                    const int rr = r - nkh;
+                    const int kww = qw + WP - 1 - rr;
+                    const bool okh = r < nkh && khh >= 0 && khh < Hp;
+                    const bool okw = rr >= 0 && rr < 2 * WP - 1 && kww >= 0 && kww < WP;
+                    const float vh = (float)*reinterpret_cast<const bf16*>(thT + (okh ? khh : 0) * 64 + ql * 2);
+                    const float vw = twg[ql * WP + (okw ? kww : 0)];
+                    gv[t] = okh ? vh : (okw ? vw : 0.f);
+                }
             }
-            const bf16x8 gf = packfrag(gv);
+        };
+        const int nstep = NRP / 16;
+        bf16x8 rf[2] = {gfrag(rcatT + (size_t)ql * NRP, 0, g), gfrag(rcatT + (size_t)(32 + ql) * NRP, 0, g)};
+        float gcur[8];
+        gather(0, gcur);
+        for (int s = 0; s < nstep; ++s) {
+            const int sn = min(s + 1, nstep - 1);
+            const bf16x8 rn[2] = {gfrag(rcatT + (size_t)ql * NRP, sn, g), gfrag(rcatT + (size_t)(32 + ql) * NRP, sn, g)};
+            float gnext[8];
+            gather(sn, gnext);
+            const bf16x8 gf = packfrag(gcur);
             *reinterpret_cast<uint4*>(dgrow + 16 * s + 8 * g) = __builtin_bit_cast(uint4, gf);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 dq[db] = mfma(rf[db], gf, dq[db]);
                 rf[db] = rn[db];
             }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) gcur[t] = gnext[t];
         }
         stage_rows(stg, dq, 1.f, lane);
         write_rows(stg, dqkv + (size_t)(b * L + qt * 32) * ldq + h * ATT_HD, ldq, lane);

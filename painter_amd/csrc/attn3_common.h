@@ -20,21 +20,18 @@ DEVI int kw_phys(int kw) { return kw < 22 ? kw : kw + 2; }
 // 16-byte chunk c = 2 s + g of a row is stored at c ^ ((i >> 2) & 3): conflict-free for the row reads (ds_read_b128) and for the
 // transposing reads (which always see 4 consecutive rows of one 4-row group).
 DEVI void build_eimg(unsigned char* eimg, int tid, int nthreads = NT) {
-    for (int idx = tid; idx < PH * 512; idx += nthreads) {
-        const int ph = idx >> 9, i = (idx >> 4) & 31, dw = idx & 15;
-        const int c = dw >> 2, s = c >> 1, g = c & 1;
+    // one thread per image row: 64 zero bytes, then the two ones (same-thread LDS writes are ordered)
+    for (int row = tid; row < PH * 32; row += nthreads) {
+        const int ph = row >> 5, i = row & 31;
         const int a = 4 * ph + i, kw = a >= WP ? a - WP : a, khr = ph + (a >= WP ? 1 : 0);        // a < 2 * WP
-        uint32_t w = 0;
+        const int sw = (i >> 2) & 3;
+        unsigned char* r = eimg + ph * EIMG + i * 64;
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int t = (dw & 3) * 2 + e;
-            bool one;
-            if (s == 0) one = kw == 8 * g + t;
-            else if (t < 6) one = kw == 16 + 6 * g + t;
-            else one = (khr & 3) == 2 * g + (t - 6);
-            if (one) w |= 0x3F80u << (16 * e);
-        }
-        *reinterpret_cast<uint32_t*>(eimg + ph * EIMG + i * 64 + ((c ^ ((i >> 2) & 3)) << 4) + (dw & 3) * 4) = w;
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(r + c * 16) = zero4();
+        const int e0 = kw_phys(kw);                                         // element = 8 * chunk + t
+        const int e1 = 16 + 8 * ((khr & 3) >> 1) + 6 + (khr & 1);           // window slot khr & 3: half-wave (slot >> 1), t = 6 + (slot & 1)
+        *reinterpret_cast<uint16_t*>(r + (((e0 >> 3) ^ sw) << 4) + (e0 & 7) * 2) = 0x3F80u;
+        *reinterpret_cast<uint16_t*>(r + (((e1 >> 3) ^ sw) << 4) + (e1 & 7) * 2) = 0x3F80u;
     }
 }
 struct EAddr {

@@ -122,9 +122,12 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
                                                       int tiles_n, int stagger) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    if (stagger > 0 && ((blockIdx.x >> 3) & 1)) {
+    // de-phasing of the first round (diagnostic knob, pa_debug_set(0, cycles)): the 256 workgroups that start together are delayed by
+    // 0 .. 15/16 of `stagger` so that their store phases do not hit HBM in one burst; later rounds inherit the phase of the CU they get
+    if (stagger > 0 && blockIdx.x < 256 && blockIdx.y == 0) {
+        const int64_t wait = ((int64_t)stagger * (((blockIdx.x >> 3) * 5) & 15)) >> 4;
         const uint64_t t0 = __builtin_amdgcn_s_memtime();
-        while ((int64_t)(__builtin_amdgcn_s_memtime() - t0) < (int64_t)stagger) __builtin_amdgcn_s_sleep(32);
+        while ((int64_t)(__builtin_amdgcn_s_memtime() - t0) < wait) __builtin_amdgcn_s_sleep(16);
     }
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wv >> 2, wc = wv & 3;
