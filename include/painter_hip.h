@@ -259,6 +259,31 @@ int pa_to_tensor_normalize(const void* images, const void* flip, float* canvas, 
  * (top, left, bh, bw).  src != dst. */
 int pa_resized_crop_f32(const float* src, float* dst, const void* boxes, int batch, int channels, int h, int w, int nearest,
                         hipStream_t stream);
+/* The same with a per-sample mode: modes = DEVICE int32 [batch], 0 bicubic, 1 nearest, 2 the sample keeps its canvas (plain copy): the
+ * samples of a step that take no second crop, or different interpolations (pairdataset.py:113-124), go through one launch. */
+int pa_resized_crop_f32_modes(const float* src, float* dst, const void* boxes, const void* modes, int batch, int channels, int h, int w,
+                              hipStream_t stream);
+/* RandomResizedCrop (pair_transforms.py:152-163 -> PIL crop + resize) for every decoded picture of a step in two launches.  jobs: DEVICE
+ * array of n_jobs descriptors; every pointer in a job is a device address.  Bicubic jobs: xbounds / ybounds = int32 [out][2] (first
+ * tap, taps), xcoeffs / ycoeffs = int32 [out][ksize] -- Pillow's fixed-point tables (painter_amd.hostmath / RS.bicubic_tables), a pass
+ * whose size does not change is skipped as in Pillow and its tables may be NULL.  Nearest jobs: xbounds = int32 [out_w] source column,
+ * ybounds = int32 [out_h] source row (PIL nearest tables), unused when the size does not change.  mid: DEVICE scratch of
+ * (sum of the bicubic jobs' h) * out_w * 3 bytes; a job's rows start at row mid_row0.  max_h / max_w: the largest box.  Bytes are
+ * identical to pa_resample_u8_box / pa_gather_u8_box applied picture by picture. */
+typedef struct pa_crop_job {
+    const void* src;            /* first pixel of the crop box, uint8 RGB, rows src_row_bytes apart */
+    void* dst;                  /* uint8 [out_h][out_w][3] */
+    const void* xbounds;
+    const void* xcoeffs;
+    const void* ybounds;
+    const void* ycoeffs;
+    int64_t src_row_bytes;
+    int32_t h, w;               /* box size */
+    int32_t xksize, yksize;
+    int32_t nearest;            /* 0 bicubic, 1 PIL nearest */
+    int32_t mid_row0;
+} pa_crop_job;
+int pa_resized_crop_u8_batch(const pa_crop_job* jobs, void* mid, int n_jobs, int max_h, int max_w, int out_h, int out_w, hipStream_t stream);
 /* `valid` rules (pairdataset.py:152-180) on float32 [batch][3][plane] targets.  modes: DEVICE int32 [batch] (0 ones; 1 target < thres
  * -> 0; 2 target > thres -> 10 and all 0 if fewer than 300 foreground elements; 3 all 0 if fewer than 300 foreground elements);
  * thres: DEVICE float [batch][3]. */

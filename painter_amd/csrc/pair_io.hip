@@ -152,11 +152,20 @@ __global__ __launch_bounds__(256) void to_tensor_kernel(const uint8_t* __restric
 DEVI float cubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
 DEVI float cubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
 
+// modes: per-sample int32 (0 bicubic, 1 nearest, 2 plain copy of the whole plane) or NULL (then `nearest` holds for every sample)
 __global__ __launch_bounds__(256) void crop_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, const int* __restrict__ boxes, int C, int H, int W,
-                                                       int nearest) {
+                                                       int nearest, const int* __restrict__ modes) {
     const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y, bc = blockIdx.z;
     if (ox >= W) return;
     const int b = bc / C;
+    if (modes != nullptr) {
+        nearest = modes[b];
+        if (nearest == 2) {
+            const size_t at = (size_t)bc * H * W + (size_t)oy * W + ox;
+            dst[at] = src[at];
+            return;
+        }
+    }
     const int top = boxes[4 * b], left = boxes[4 * b + 1], bh = boxes[4 * b + 2], bw = boxes[4 * b + 3];
     const float* s = src + (size_t)bc * H * W;
     float* d = dst + (size_t)bc * H * W + (size_t)oy * W + ox;
@@ -184,6 +193,103 @@ __global__ __launch_bounds__(256) void crop_f32_kernel(const float* __restrict__
         acc += rowv * wy[j];
     }
     *d = acc;
+}
+
+// ---- RandomResizedCrop for every picture of a step in two launches (pa_resized_crop_u8_batch).  A job = one decoded picture's crop
+// box -> one [out_h][out_w][3] output.  Pillow order: horizontal pass into `mid` (all h rows of the box; a plain copy when the width
+// does not change, as Pillow skips the pass), then the vertical pass (a copy when the height does not change).  PIL-nearest jobs are
+// one gather in the second launch.  The arithmetic is resample_h_lds_kernel's / resample_u8_kernel<true>'s / gather_u8_kernel's
+// (csrc/seggpt_io.hip), so the bytes are the per-picture entry points' bytes.
+constexpr int CROP_PRECISION_BITS = 32 - 8 - 2;          // Pillow Resample.c
+DEVI uint8_t crop_clip8(int acc) {
+    const int v = acc >> CROP_PRECISION_BITS;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+__global__ __launch_bounds__(256) void crop_u8_h_kernel(const pa_crop_job* __restrict__ jobs, uint8_t* __restrict__ mid, int out_w) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char row_lds[];
+    const pa_crop_job jb = jobs[blockIdx.y];
+    const int y = blockIdx.x, tid = threadIdx.x;
+    if (y >= jb.h || jb.nearest) return;
+    const uint8_t* row = (const uint8_t*)jb.src + (size_t)y * jb.src_row_bytes;
+    uint8_t* drow = mid + ((size_t)jb.mid_row0 + y) * out_w * 3;
+    const int nbytes = jb.w * 3;
+    if (jb.w == out_w) {
+        for (int i = tid; i < nbytes; i += 256) drow[i] = row[i];
+        return;
+    }
+    const int off = (int)((uintptr_t)row & 3);
+    int head = (4 - off) & 3;
+    if (head > nbytes) head = nbytes;
+    const int ndw = (nbytes - head) >> 2, tail0 = head + 4 * ndw;
+    if (tid < head) row_lds[off + tid] = row[tid];
+    const uint32_t* rp = (const uint32_t*)(row + head);
+    uint32_t* lp = (uint32_t*)(row_lds + off + head);
+    for (int i = tid; i < ndw; i += 256) lp[i] = rp[i];
+    if (tid < nbytes - tail0) row_lds[off + tail0 + tid] = row[tail0 + tid];
+    __syncthreads();
+    const unsigned char* r = row_lds + off;
+    const int* bounds = (const int*)jb.xbounds;
+    const int* coeffs = (const int*)jb.xcoeffs;
+    for (int x = tid; x < out_w; x += 256) {
+        const int first = bounds[2 * x], taps = bounds[2 * x + 1];
+        const int* k = coeffs + (size_t)x * jb.xksize;
+        int a0 = 1 << (CROP_PRECISION_BITS - 1), a1 = a0, a2 = a0;
+        const unsigned char* sp = r + first * 3;
+        for (int t = 0; t < taps; ++t, sp += 3) {
+            const int kt = k[t];
+            a0 += (int)sp[0] * kt;
+            a1 += (int)sp[1] * kt;
+            a2 += (int)sp[2] * kt;
+        }
+        drow[3 * x] = crop_clip8(a0);
+        drow[3 * x + 1] = crop_clip8(a1);
+        drow[3 * x + 2] = crop_clip8(a2);
+    }
+}
+__global__ __launch_bounds__(256) void crop_u8_v_kernel(const pa_crop_job* __restrict__ jobs, const uint8_t* __restrict__ mid, int out_h, int out_w) {
+    const pa_crop_job jb = jobs[blockIdx.z];
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= out_w) return;
+    uint8_t* d = (uint8_t*)jb.dst + ((size_t)y * out_w + x) * 3;
+    if (jb.nearest) {
+        int sy = y, sx = x;
+        if (jb.h != out_h || jb.w != out_w) {               // PIL returns a copy when the size does not change
+            sy = ((const int*)jb.ybounds)[y];
+            sx = ((const int*)jb.xbounds)[x];
+        }
+        if (sy < 0 || sx < 0) {
+            d[0] = d[1] = d[2] = 0;
+            return;
+        }
+        const uint8_t* sp = (const uint8_t*)jb.src + (size_t)sy * jb.src_row_bytes + (size_t)sx * 3;
+        d[0] = sp[0];
+        d[1] = sp[1];
+        d[2] = sp[2];
+        return;
+    }
+    const size_t mrow = (size_t)out_w * 3;
+    const uint8_t* m0 = mid + (size_t)jb.mid_row0 * mrow + (size_t)x * 3;
+    if (jb.h == out_h) {
+        const uint8_t* sp = m0 + (size_t)y * mrow;
+        d[0] = sp[0];
+        d[1] = sp[1];
+        d[2] = sp[2];
+        return;
+    }
+    const int* bounds = (const int*)jb.ybounds;
+    const int first = bounds[2 * y], taps = bounds[2 * y + 1];
+    const int* k = (const int*)jb.ycoeffs + (size_t)y * jb.yksize;
+    int a0 = 1 << (CROP_PRECISION_BITS - 1), a1 = a0, a2 = a0;
+    const uint8_t* sp = m0 + (size_t)first * mrow;
+    for (int t = 0; t < taps; ++t, sp += mrow) {
+        const int kt = k[t];
+        a0 += (int)sp[0] * kt;
+        a1 += (int)sp[1] * kt;
+        a2 += (int)sp[2] * kt;
+    }
+    d[0] = crop_clip8(a0);
+    d[1] = crop_clip8(a1);
+    d[2] = crop_clip8(a2);
 }
 
 // ---- `valid` rules (pairdataset.py:152-180).  modes: 0 ones, 1 (target < thres -> 0), 2 pose (target > thres -> 10, fewer than 300
@@ -263,7 +369,25 @@ int pa_resized_crop_f32(const float* src, float* dst, const void* boxes, int bat
                         hipStream_t stream) {
     if (batch < 1 || channels < 1 || (int64_t)batch * channels > 65535 || h < 1 || h > 65535 || w < 1 || src == dst) return (int)hipErrorInvalidValue;
     PA_LAUNCH(crop_f32_kernel, dim3(blocks(w), (unsigned)h, (unsigned)(batch * channels)), dim3(256), 0, stream, src, dst, (const int*)boxes, channels, h, w,
-              nearest);
+              nearest, (const int*)nullptr);
+    LAUNCH_CHECK();
+}
+
+int pa_resized_crop_f32_modes(const float* src, float* dst, const void* boxes, const void* modes, int batch, int channels, int h, int w,
+                              hipStream_t stream) {
+    if (batch < 1 || channels < 1 || (int64_t)batch * channels > 65535 || h < 1 || h > 65535 || w < 1 || src == dst || modes == nullptr)
+        return (int)hipErrorInvalidValue;
+    PA_LAUNCH(crop_f32_kernel, dim3(blocks(w), (unsigned)h, (unsigned)(batch * channels)), dim3(256), 0, stream, src, dst, (const int*)boxes, channels, h, w,
+              0, (const int*)modes);
+    LAUNCH_CHECK();
+}
+
+int pa_resized_crop_u8_batch(const pa_crop_job* jobs, void* mid, int n_jobs, int max_h, int max_w, int out_h, int out_w, hipStream_t stream) {
+    if (n_jobs < 1 || n_jobs > 65535 || max_h < 1 || max_w < 1 || out_h < 1 || out_h > 65535 || out_w < 1) return (int)hipErrorInvalidValue;
+    const size_t lds = ((size_t)max_w * 3 + 8 + 15) & ~(size_t)15;
+    if (lds > 64 * 1024) return (int)hipErrorInvalidValue;          // a source row is staged in LDS
+    PA_LAUNCH(crop_u8_h_kernel, dim3((unsigned)max_h, (unsigned)n_jobs), dim3(256), lds, stream, jobs, (uint8_t*)mid, out_w);
+    PA_LAUNCH(crop_u8_v_kernel, dim3(blocks(out_w), (unsigned)out_h, (unsigned)n_jobs), dim3(256), 0, stream, jobs, (const uint8_t*)mid, out_h, out_w);
     LAUNCH_CHECK();
 }
 

@@ -144,6 +144,8 @@ class DevicePairPipeline:
         self.H, self.W = input_size
         self.side = input_size[1]                      # RandomResizedCrop(args.input_size[1]) -> side x side (main_train.py:234)
         self._tables = {}
+        self._pin = None                               # pinned staging buffer for the packed crop boxes
+        self._pin_event = None
 
     def _table(self, kind, in_size, out_size):
         key = (kind, in_size, out_size)
@@ -248,39 +250,116 @@ class DevicePairPipeline:
               "pa_pair_valid")
         return valid
 
+    # ---- RandomResizedCrop of every picture of a step: one upload, two launches
+    _JOB = np.dtype([("src", "<u8"), ("dst", "<u8"), ("xbounds", "<u8"), ("xcoeffs", "<u8"), ("ybounds", "<u8"), ("ycoeffs", "<u8"),
+                     ("src_row_bytes", "<i8"), ("h", "<i4"), ("w", "<i4"), ("xksize", "<i4"), ("yksize", "<i4"), ("nearest", "<i4"),
+                     ("mid_row0", "<i4")])          # include/painter_hip.h: pa_crop_job
+
+    def resized_crop_batch(self, pictures, boxes, nearest, out):
+        """pictures: decoded uint8 [H][W][3] numpy arrays; boxes: (top, left, h, w) each; nearest: bool each; out: uint8
+        [n][side][side][3] CUDA tensor written in place.  Only the crop boxes travel to the device, packed in one pinned buffer."""
+        n = len(pictures)
+        oh, ow = out.shape[1], out.shape[2]
+        assert out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.shape[0] == n and out.shape[3] == 3
+        sizes = []
+        for pic, (i, j, h, w) in zip(pictures, boxes):
+            H, W = pic.shape[:2]
+            assert pic.dtype == np.uint8 and pic.ndim == 3 and pic.shape[2] == 3
+            assert 0 <= i and 0 <= j and h >= 1 and w >= 1 and i + h <= H and j + w <= W, ((i, j, h, w), (H, W))
+            sizes.append((h * w * 3 + 15) & ~15)
+        total = sum(sizes)
+        if self._pin_event is not None:
+            self._pin_event.synchronize()               # the previous step's upload has left the staging buffer
+        if self._pin is None or self._pin.numel() < total:
+            self._pin = torch.empty(max(total, 1 << 22), dtype=torch.uint8).pin_memory()
+        pin = self._pin.numpy()
+        off = 0
+        offs = []
+        for pic, (i, j, h, w), sz in zip(pictures, boxes, sizes):
+            pin[off:off + h * w * 3].reshape(h, w, 3)[...] = pic[i:i + h, j:j + w]
+            offs.append(off)
+            off += sz
+        dev = torch.empty(total, dtype=torch.uint8, device=self.device)
+        dev.copy_(self._pin[:total], non_blocking=True)
+        self._pin_event = torch.cuda.Event()
+        self._pin_event.record()
+        jobs = np.zeros(n, self._JOB)
+        mid_rows = 0
+        keep = []
+        for k, ((i, j, h, w), near) in enumerate(zip(boxes, nearest)):
+            jobs["src"][k], jobs["dst"][k] = dev.data_ptr() + offs[k], out[k].data_ptr()
+            jobs["src_row_bytes"][k], jobs["h"][k], jobs["w"][k], jobs["nearest"][k] = w * 3, h, w, 1 if near else 0
+            if near:
+                if (h, w) != (oh, ow):
+                    yt, xt = self._table("pil_nearest", h, oh), self._table("pil_nearest", w, ow)
+                    jobs["ybounds"][k], jobs["xbounds"][k] = yt.data_ptr(), xt.data_ptr()
+                    keep += [yt, xt]
+                continue
+            jobs["mid_row0"][k] = mid_rows
+            mid_rows += h
+            if w != ow:
+                tb, tc, ks = self._table("bicubic", w, ow)
+                jobs["xbounds"][k], jobs["xcoeffs"][k], jobs["xksize"][k] = tb.data_ptr(), tc.data_ptr(), ks
+                keep += [tb, tc]
+            if h != oh:
+                tb, tc, ks = self._table("bicubic", h, oh)
+                jobs["ybounds"][k], jobs["ycoeffs"][k], jobs["yksize"][k] = tb.data_ptr(), tc.data_ptr(), ks
+                keep += [tb, tc]
+        jobs_d = torch.from_numpy(jobs.view(np.uint8).reshape(-1)).to(self.device)
+        mid = torch.empty(max(mid_rows, 1) * ow * 3, dtype=torch.uint8, device=self.device)
+        check(lib.pa_resized_crop_u8_batch(jobs_d.data_ptr(), mid.data_ptr(), n, max(b[2] for b in boxes), max(b[3] for b in boxes), oh, ow,
+                                           _stream()), "pa_resized_crop_u8_batch")
+        del keep                                        # the tables stay referenced by the cache until the launches are enqueued
+        return out
+
+    def resized_crop_tensor_modes(self, canvas, boxes, modes):
+        """canvas: float32 [B][C][H][W]; boxes [B][4]; modes [B] (0 bicubic, 1 nearest, 2 keep) -> new canvas, one launch."""
+        B, C, H, W = canvas.shape
+        out = torch.empty_like(canvas)
+        box_d = torch.as_tensor(np.asarray(boxes, np.int32).reshape(B, 4)).to(self.device)
+        mode_d = torch.as_tensor(np.asarray(modes, np.int32).reshape(B)).to(self.device)
+        check(lib.pa_resized_crop_f32_modes(canvas.data_ptr(), out.data_ptr(), box_d.data_ptr(), mode_d.data_ptr(), B, C, H, W, _stream()),
+              "pa_resized_crop_f32_modes")
+        return out
+
     # ---- a whole step
     def build_batch(self, samples: Sequence[SampleSpec]):
-        """-> (imgs, tgts, valid) float32 [B][3][H][W] on the device, what `collate(__getitem__ ...)` hands to the model."""
+        """-> (imgs, tgts, valid) float32 [B][3][H][W] on the device, what `collate(__getitem__ ...)` hands to the model.
+        Launches per step (two-pair samples): 2 for every crop of the step (images and targets of both pairs are jobs of one table),
+        <= 8 for the jitter (one sum + one apply per used slot, both pairs in one call), 4 ToTensor/Normalize/stitch, 2 second crops,
+        2 valid -- independent of the batch size; uploads: the packed crop boxes, the job table, and five small parameter arrays."""
         B = len(samples)
         npairs = len(samples[0].pairs)
         assert npairs in (1, 2) and all(len(s.pairs) == npairs for s in samples) and npairs * self.side == self.H, \
             "input_size %s needs %d pair(s) of %d rows" % ((self.H, self.W), self.H // self.side, self.side)
         imgs = torch.empty((B, 3, self.H, self.W), dtype=torch.float32, device=self.device)
         tgts = torch.empty_like(imgs)
+        # crops[0] = images, crops[1] = targets; row k * B + b = pair k of sample b
+        crops = torch.empty((2, npairs * B, self.side, self.side, 3), dtype=torch.uint8, device=self.device)
+        pictures, boxes, nearest = [], [], []
+        for which in range(2):
+            for k in range(npairs):
+                for s in samples:
+                    p = s.pairs[k]
+                    assert p.image.shape == p.target.shape, "image and target of a pair share one crop box (pair_transforms.py:152-163)"
+                    pictures.append(p.target if which else p.image)
+                    boxes.append(p.crop)
+                    nearest.append(s.interpolation[which] == "nearest")
+        self.resized_crop_batch(pictures, boxes, nearest, crops.view(2 * npairs * B, self.side, self.side, 3))
+        order = [(k, s) for k in range(npairs) for s in samples]
+        self.color_jitter(crops[0], [s.pairs[k].jitter_ops for k, s in order], [s.pairs[k].jitter_factors for k, s in order])
         for k in range(npairs):
-            a = torch.empty((B, self.side, self.side, 3), dtype=torch.uint8, device=self.device)
-            t = torch.empty_like(a)
-            for b, s in enumerate(samples):
-                p = s.pairs[k]
-                pic = torch.from_numpy(np.ascontiguousarray(p.image)).to(self.device)
-                tpic = torch.from_numpy(np.ascontiguousarray(p.target)).to(self.device)
-                assert pic.shape == tpic.shape, "image and target of a pair share one crop box (pair_transforms.py:152-163)"
-                self.resized_crop(pic, p.crop, a[b], s.interpolation[0] == "nearest")
-                self.resized_crop(tpic, p.crop, t[b], s.interpolation[1] == "nearest")
-            self.color_jitter(a, [s.pairs[k].jitter_ops for s in samples], [s.pairs[k].jitter_factors for s in samples])
             flips = [s.pairs[k].flip for s in samples]
-            self.to_tensor_normalize(a, flips, imgs, k * self.side)
-            self.to_tensor_normalize(t, flips, tgts, k * self.side)
-        # second crop: per sample either a box or the identity; both interpolation modes may occur in one batch
-        sec = [b for b, s in enumerate(samples) if s.seccrop is not None]
-        if sec:
-            boxes = [samples[b].seccrop if samples[b].seccrop is not None else (0, 0, self.H, self.W) for b in range(B)]
-            for canvas, side in ((imgs, 0), (tgts, 1)):
-                near = [samples[b].interpolation[side] == "nearest" for b in range(B)]
-                for mode in (False, True):
-                    idx = [b for b in sec if near[b] == mode]
-                    if idx:
-                        sel = torch.as_tensor(idx, device=self.device)
-                        canvas[sel] = self.resized_crop_tensor(canvas[sel].contiguous(), [boxes[b] for b in idx], mode)
+            self.to_tensor_normalize(crops[0, k * B:(k + 1) * B], flips, imgs, k * self.side)
+            self.to_tensor_normalize(crops[1, k * B:(k + 1) * B], flips, tgts, k * self.side)
+        # second crop: per sample a box and an interpolation mode, or "keep"
+        if any(s.seccrop is not None for s in samples):
+            boxes2 = [s.seccrop if s.seccrop is not None else (0, 0, self.H, self.W) for s in samples]
+            for side, name in ((0, "imgs"), (1, "tgts")):
+                modes = [2 if s.seccrop is None else (1 if s.interpolation[side] == "nearest" else 0) for s in samples]
+                if side == 0:
+                    imgs = self.resized_crop_tensor_modes(imgs, boxes2, modes)
+                else:
+                    tgts = self.resized_crop_tensor_modes(tgts, boxes2, modes)
         valid = self.valid_map(tgts, [s.pair_type for s in samples])
         return imgs, tgts, valid

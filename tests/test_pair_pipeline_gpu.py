@@ -39,6 +39,37 @@ def test_device_resized_crop_is_pil_crop_then_resize(pipe, h, w, box, size):
         assert np.array_equal(out.cpu().numpy(), np.array(crop.resize((size[1], size[0]), flt))), nearest
 
 
+def test_batched_resized_crop_is_pil_crop_then_resize_for_every_job(pipe):
+    """pa_resized_crop_u8_batch: one job table for pictures of different sizes, boxes and interpolations (both passes, one pass skipped,
+    both skipped, nearest with and without a size change), two launches -- every output equals PIL crop + resize."""
+    cases = [(480, 640, (30, 50, 400, 500), False), (375, 500, (0, 0, 375, 500), True), (300, 701, (17, 123, 280, 333), False),
+             (448, 448, (0, 0, 448, 448), False), (448, 448, (0, 0, 448, 448), True), (600, 450, (100, 1, 448, 300), False),
+             (600, 450, (100, 1, 300, 448), False), (64, 67, (5, 7, 9, 11), True), (64, 67, (5, 7, 9, 11), False),
+             (1200, 1999, (3, 5, 1100, 1901), False), (120, 97, (22, 31, 68, 55), True)]
+    pictures = [picture(7 * k + h + w, h, w) for k, (h, w, _, _) in enumerate(cases)]
+    out = torch.zeros((len(cases), 448, 448, 3), dtype=torch.uint8, device="cuda")
+    for _ in range(2):                                          # twice: the second call reuses the pinned staging buffer and the tables
+        pipe.resized_crop_batch(pictures, [c[2] for c in cases], [c[3] for c in cases], out)
+        got = out.cpu().numpy()
+        for k, (h, w, (i, j, bh, bw), near) in enumerate(cases):
+            ref = np.array(Image.fromarray(pictures[k]).crop((j, i, j + bw, i + bh)).resize((448, 448), Image.NEAREST if near else Image.BICUBIC))
+            assert np.array_equal(got[k], ref), (k, cases[k])
+        out.zero_()
+
+
+def test_second_crop_with_per_sample_modes_matches_the_single_mode_entry(pipe):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(5, 3, 896, 448, generator=g).cuda()
+    boxes = [(10, 20, 700, 300), (0, 0, 896, 448), (100, 3, 512, 256), (5, 5, 448, 224), (0, 0, 896, 448)]
+    modes = [0, 2, 1, 0, 1]
+    got = pipe.resized_crop_tensor_modes(x, boxes, modes)
+    bic = pipe.resized_crop_tensor(x, boxes, False)
+    near = pipe.resized_crop_tensor(x, boxes, True)
+    for b, m in enumerate(modes):
+        ref = x[b] if m == 2 else (near[b] if m == 1 else bic[b])
+        assert torch.equal(got[b], ref), b
+
+
 def _jitter_batch():
     ops = [(PP.CONTRAST, PP.HUE, PP.BRIGHTNESS, PP.SATURATION), (PP.BRIGHTNESS, PP.SATURATION, PP.CONTRAST, PP.HUE), (),
            (PP.HUE, PP.SATURATION, PP.BRIGHTNESS, PP.CONTRAST), (PP.SATURATION,), (PP.CONTRAST, PP.CONTRAST, PP.HUE, PP.HUE)]
@@ -146,3 +177,6 @@ def test_c_abi_rejects_bad_arguments():
     assert lib.pa_resized_crop_f32(p, p, p, 1, 3, 4, 4, 0, s) != 0                                 # in place
     assert lib.pa_color_jitter(p, p, p, None, p, 0, 4, 4, s) != 0
     assert lib.pa_pair_valid(p, p, p, p, p, 1, 0, s) != 0
+    assert lib.pa_resized_crop_f32_modes(p, p + 64, p, None, 1, 3, 4, 4, s) != 0                   # no modes array
+    assert lib.pa_resized_crop_u8_batch(p, p, 0, 4, 4, 4, 4, s) != 0                               # no jobs
+    assert lib.pa_resized_crop_u8_batch(p, p, 1, 4, 30000, 4, 4, s) != 0                           # a source row must fit the LDS stage
