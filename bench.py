@@ -132,7 +132,7 @@ class KernelTimer:
         return out
 
 
-def cpu_baseline(budget_s=30.0):
+def cpu_baseline(budget_s=60.0):
     """The CPU oracle at B=1 (ViT-L, 896x448, fp32) on the host's physical cores: train forward+backward (1 warm-up + up to 3 timed
     runs) and eval forward (up to 3 timed runs after the warm-up above), time-boxed to about `budget_s` seconds of timed work so that
     the default bench run stays within minutes (at least one timed run of each is always taken)."""

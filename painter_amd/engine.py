@@ -371,6 +371,9 @@ class HotPath:
         ready(["norm.weight", "norm.bias", "patch_embed.proj.weight", "patch_embed.proj.bias", "pos_embed",
                "segment_token_x", "segment_token_y", "mask_token"])
         if side is not None:
+            if getattr(self, "tail_probe", None) is not None:      # diagnostics (tools/step_tail.py): when each stream ran dry
+                self.tail_probe[0].record(main)
+                self.tail_probe[1].record(side)
             main.wait_stream(side)                 # every gradient is ordered before whatever the caller enqueues next
         if keep:
             torch.cuda.synchronize()

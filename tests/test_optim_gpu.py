@@ -136,3 +136,70 @@ def test_fused_step_invalidates_the_engines_bf16_weight_cache(bind):
     loss2, _, _ = m2(*args, **kw())
     assert abs(loss1.item() - loss2.item()) <= 1e-6 * abs(loss2.item()), (loss0.item(), loss1.item(), loss2.item())
     assert abs(loss1.item() - loss0.item()) > 1e-4 * abs(loss0.item())          # and the step did change something
+
+
+def test_state_dict_of_multi_parameter_groups_loads_into_torch_adamw():
+    """Our state_dict() -> torch.optim.AdamW.load_state_dict(): every parameter carries its OWN 0-d `step` tensor (torch's foreach
+    step increments them in place: a tensor shared by the parameters of a group would be advanced once per parameter)."""
+    import copy
+    g, params, _ = _make(9)
+    mk = lambda: [torch.nn.Parameter(p.clone().cuda()) for p in params]
+    ours_p, torch_p = mk(), mk()
+    groups = lambda ps: [{"params": [p for p in ps if p.ndim > 1], "weight_decay": 0.05}, {"params": [p for p in ps if p.ndim <= 1], "weight_decay": 0.0}]
+    ours = PO.AdamW(groups(ours_p), lr=2e-3, betas=(0.9, 0.95))
+    ws = [torch.randn(s, generator=g).cuda() for s in SHAPES]
+
+    def one_step(ps, o):
+        o.zero_grad()
+        sum((w * p * p).sum() for w, p in zip(ws, ps)).backward()
+        o.step()
+
+    for _ in range(3):
+        one_step(ours_p, ours)
+    sd = ours.state_dict()
+    steps = [st["step"] for st in sd["state"].values()]
+    assert len({t.data_ptr() for t in steps}) == len(steps) and all(float(t) == 3.0 for t in steps)
+    ref = torch.optim.AdamW(groups(torch_p), lr=2e-3, betas=(0.9, 0.95))
+    with torch.no_grad():
+        for a, b in zip(torch_p, ours_p):
+            a.copy_(b)
+    ref.load_state_dict(copy.deepcopy(sd))
+    for _ in range(2):                                           # both continue from step 3
+        one_step(ours_p, ours)
+        one_step(torch_p, ref)
+    assert all(float(st["step"]) == 5.0 for st in ref.state_dict()["state"].values())
+    for a, b in zip(ours_p, torch_p):
+        assert torch.allclose(a.detach(), b.detach(), rtol=2e-6, atol=1e-7)
+
+
+def test_step_is_skipped_when_the_sum_of_squares_overflows():
+    """Finite gradients whose fp32 sum of squares is inf (norm = inf): torch's clip would scale by 0 / produce NaN; the fused step must
+    leave parameters and moments untouched, as it does for an inf gradient."""
+    p = torch.nn.Parameter(torch.ones(4096, device="cuda"))
+    opt = PO.AdamW([p], lr=1e-2)
+    p.grad = torch.full_like(p, 3e19)                            # (3e19)^2 * 4096 > fp32 max
+    before = p.detach().clone()
+    opt.step(max_norm=1.0)
+    assert torch.equal(p.detach(), before)
+    p.grad = torch.full_like(p, 1.0)
+    opt.step(max_norm=1.0)
+    assert not torch.equal(p.detach(), before)
+
+
+def test_gradient_buffers_replaced_between_steps_are_picked_up():
+    """`p.grad = new_tensor` between steps (what autograd does after zero_grad(set_to_none=True)) must not leave the launcher's cached
+    pointer table aimed at the old buffers."""
+    g, params, cfg = _make(21)
+    ours_p = [torch.nn.Parameter(p.clone().cuda()) for p in params]
+    ref_p = [torch.nn.Parameter(p.clone().cuda()) for p in params]
+    ours, ref = PO.AdamW(ours_p, lr=1e-3), torch.optim.AdamW(ref_p, lr=1e-3)
+    keep = []
+    for it in range(3):
+        grads = [torch.randn(s, generator=g).cuda() for s in SHAPES]
+        keep.append(grads)                                       # old buffers stay alive, so a stale pointer would read valid but wrong data
+        for p, q, gr in zip(ours_p, ref_p, grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        ours.step()
+        ref.step()
+    for a, b in zip(ours_p, ref_p):
+        assert torch.allclose(a.detach(), b.detach(), rtol=2e-6, atol=1e-7)
