@@ -25,7 +25,7 @@ namespace g256 {
 
 constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
 constexpr int LDS_BYTES = 131072;
-// diagnostics (pa_debug_set): [0] start-up stagger of every other workgroup row in shader cycles, [1] drop epilogue stores
+// diagnostics (pa_debug_set): [0] first-round de-phasing in shader cycles, [1] drop epilogue stores, [2] 1 = plain row-major tile order, [3] wgrad workgroup target
 inline int g_dbg[4] = {0, 0, 0, 0};
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
@@ -119,7 +119,7 @@ template <> struct Frag4<true> {
 template <bool AMM, bool BMM, class Epi>
 __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag, uint32_t lda, const bf16* __restrict__ Bg,
                                                       uint32_t ldb, Epi epi, int M, int N, int ktiles, int ktiles_per_split,
-                                                      int tiles_n, int stagger) {
+                                                      int tiles_n, int stagger, int order) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // de-phasing of the first round (diagnostic knob, pa_debug_set(0, cycles)): the 256 workgroups that start together are delayed by
@@ -137,7 +137,31 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
     const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    // Inside the run the tiles are ordered in blocks of TR row panels x TC column panels (row groups of TR panels, column blocks of TC,
+    // then row-major inside a block), so that the ~32 tiles an XCD has in flight form a TR x TC patch: per contraction step they pull
+    // TR + TC operand panels through that XCD's L2 instead of 2 + tiles_n (fc1 forward, 16 column panels: FETCH_SIZE 251 -> ~165 MB
+    // per launch; the weight matrix alone is twice the L2).  g_dbg[2] = 1 restores the plain row-major order (A/B).
+    int tm, tn;
+    if (order == 0) {
+        constexpr int TR = 4, TC = 8;
+        const int tiles_m = (M + BM - 1) / BM;
+        const int per_group = TR * tiles_n;
+        const int gm = tile / per_group, rem = tile - gm * per_group;
+        const int rg = min(TR, tiles_m - gm * TR);                   // row panels in this (possibly last, shorter) group
+        const int full = tiles_n / TC;                               // full column blocks
+        int cb = rem / (rg * TC), r2 = rem - cb * (rg * TC), cw = TC;
+        if (cb >= full) {                                            // the narrower last column block
+            cb = full;
+            r2 = rem - full * (rg * TC);
+            cw = tiles_n - full * TC;
+        }
+        const int dm = r2 / cw;
+        tm = gm * TR + dm;
+        tn = cb * TC + (r2 - dm * cw);
+    } else {
+        tm = tile / tiles_n;
+        tn = tile - tm * tiles_n;
+    }
     const int i0 = tm * BM, j0 = tn * BN;
     const int split = blockIdx.y;
     const int kt0 = split * ktiles_per_split;
@@ -351,7 +375,7 @@ static int launch(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi,
     const int splits = (ktiles + per - 1) / per;      // every split gets an even number (>= 2) of tiles
     if (g_dbg[1]) epi.M = 0;
     PA_LAUNCH(kern, dim3(tiles_m * tiles_n, splits), dim3(NT), LDS_BYTES, st, A, (uint32_t)lda, B, (uint32_t)ldb, epi, M, N,
-              ktiles, per, tiles_n, g_dbg[0]);
+              ktiles, per, tiles_n, g_dbg[0], g_dbg[2]);
     return (int)hipGetLastError();
 }
 // shapes the kernel accepts; everything else stays on the generic engine (gemm_engine.h)

@@ -34,6 +34,11 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def fro(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
 def tile_err(a, b, rows):
     """max abs error per 32-row tile, relative to the global max of b"""
     a, b = a.double().reshape(rows, -1), b.double().reshape(rows, -1)
@@ -68,6 +73,9 @@ def main():
                         dk=rel(dqkv[:, D:2 * D], q64.grad[:, D:2 * D]), dv=rel(dqkv[:, 2 * D:], q64.grad[:, 2 * D:]),
                         drh=rel(drcat[:nh], rh64.grad), drw=rel(drcat[nh:nh + nw], rw64.grad))
             print("shape", (B, H, Hp, Wp), "gen", {0: "3 4-wave", 5: "3 pipelined dq", 4: "3 paired", 2: "2"}[gen_], {k: "%.2e" % v for k, v in errs.items()}, flush=True)
+            fros = dict(out=fro(out, ref.detach()), dq=fro(dqkv[:, :D], q64.grad[:, :D]), dk=fro(dqkv[:, D:2 * D], q64.grad[:, D:2 * D]),
+                        dv=fro(dqkv[:, 2 * D:], q64.grad[:, 2 * D:]), drh=fro(drcat[:nh], rh64.grad), drw=fro(drcat[nh:nh + nw], rw64.grad))
+            print("      relative Frobenius", {k: "%.2e" % v for k, v in fros.items()}, flush=True)
             if gen_ != 2 and max(errs.values()) > 3e-2:
                 torch.set_printoptions(precision=2, linewidth=250)
                 print("  out tiles ", tile_err(out, ref.detach(), B * L)[:64])
