@@ -196,10 +196,10 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     const int trwg = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : -1);
     auto coarse = [&](int pt) {          // traced build: stamps 60 kernel start, 61 loop start, 62 loop end, 63 kernel end (slot 0 of each)
         if constexpr (TR) {
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (trwg >= 0 && wave < 2 && lane == 0) g_trace[((trwg * 2 + wave) * 64 + pt) * 8] = t;
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
         }
     };
     coarse(60);
@@ -271,10 +271,10 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         const int j = a * PH + P;
         auto mark = [&](int pt) {
             if constexpr (TR) {
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
                 const unsigned long long t = __builtin_amdgcn_s_memtime();
                 if (trwg >= 0 && wave < 2 && lane == 0 && j < 60) g_trace[((trwg * 2 + wave) * 64 + j) * 8 + pt] = t;
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
             }
         };
         mark(0);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             bf16x8 kfr[4], vfr[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) { vfr[s] = rowfrag(vimg, la, s); kfr[s] = rowfrag(kimg, la, s); }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
             if constexpr (TR) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
             mark(1);
             f32x16 sacc = zero16(), dpacc;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             for (int db = 0; db < 2; ++db) { ktr[db][0] = trfrag(kimg, la, db, 0); ktr[db][1] = trfrag(kimg, la, db, 1); }
             etr[0] = etrfrag(ei, ea, 0);
             etr[1] = etrfrag(ei, ea, 1);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
             mark(2);
             float ds[16];
 #pragma unroll
@@ -554,7 +554,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
             bf16x8 qfr[4], dofr[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) { qfr[s] = rowfrag(qimg, la, s); dofr[s] = rowfrag(doimg, la, s); }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);
             a1.w = wlo | (whi << 16);
             f32x16 sacc = zero16();
             sacc = mfma(as_frag(a0), eb0, sacc);                          // S[q][key] - lse: lane = key, registers = q rows
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
                 dotr[db][0] = trfrag(doimg, la, db, 0); dotr[db][1] = trfrag(doimg, la, db, 1);
                 qtr[db][0] = trfrag(qimg, la, db, 0); qtr[db][1] = trfrag(qimg, la, db, 1);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);
             float p[16], ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -689,7 +689,8 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
     if (attn3_pipelined() && !g_attn_trace) {
         if ((e = attn3s_dq(qkv, ldq, rcatT, dout, lddo, lse, tables, dqkv, dG, Bn, L, H, Hp, Wp, scale, st))) return e;
     } else {
-        const size_t smem = 2 * (size_t)STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG;
+        static const size_t pad = [] { const char* v = getenv("PA_ATTN3_LDS_PAD"); return v ? (size_t)atoi(v) : (size_t)0; }();   // diagnostics: fewer workgroups per CU
+        const size_t smem = 2 * (size_t)STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG + pad;
         auto kern = g_attn_trace ? bwd_dq_kernel<2, true, true> : (dq_w == 3 ? bwd_dq_kernel<3, false> : bwd_dq_kernel<2, true>);
         static bool done2 = false, done3 = false, donet = false;
         if ((e = set_smem(reinterpret_cast<const void*>(kern), g_attn_trace ? donet : (dq_w == 3 ? done3 : done2)))) return e;
@@ -700,6 +701,8 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
     {
         size_t smem = 2 * (size_t)DKV_STAGE;
         if (smem < (size_t)NW * 2 * IMG) smem = (size_t)NW * 2 * IMG;
+        static const size_t pad = [] { const char* v = getenv("PA_ATTN3_LDS_PAD"); return v ? (size_t)atoi(v) : (size_t)0; }();
+        smem += pad;
         auto kern = dkv_w == 3 ? bwd_dkv_kernel<3> : bwd_dkv_kernel<2>;
         static bool done2 = false, done3 = false;
         if ((e = set_smem(reinterpret_cast<const void*>(kern), dkv_w == 3 ? done3 : done2))) return e;

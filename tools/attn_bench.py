@@ -38,16 +38,16 @@ def main():
         rcat = ops.relpos_pack(rel_h, rel_w, Hp, Wp, T)
         rcatT = ops.relpos_pack_t(rel_h, rel_w, Hp, Wp, T)
         fl = 4.0 * B * H * L * L * 64
-        res = {2: [], 5: [], 0: []}
+        res = {2: [], 5: [], 0: [], 4: []}
         for _ in range(rounds):
-            for gen_ in (2, 0, 5):
+            for gen_ in (2, 0, 5, 4):
                 lib.pa_attn_set_generation(gen_)
                 out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
                 tf = timeit(lambda: ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True))
                 tb = timeit(lambda: ops.attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables))
                 res[gen_].append((tf, tb))
         lib.pa_attn_set_generation(0)
-        for gen_, name in ((2, "gen2"), (0, "gen3 4-wave"), (5, "gen3 pipelined dq")):
+        for gen_, name in ((2, "gen2"), (0, "gen3 4-wave"), (5, "gen3 pipelined dq"), (4, "gen3 paired 8-wave")):
             tf = min(r[0] for r in res[gen_])
             tb = min(r[1] for r in res[gen_])
             print("B'=%d %s  fwd %.3f ms (%.0f TFLOP/s)   bwd core %.3f ms (%.0f TFLOP/s algorithmic, 2.5x fwd)   all rounds fwd %s bwd %s"
