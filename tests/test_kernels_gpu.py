@@ -242,7 +242,7 @@ def test_attn_fwd(T, B, H, Hp, Wp, gen_, attn_generation):
     ref, lse_ref = attn_reference(qkv, rcat[: 2 * Hp - 1], rcat[2 * Hp - 1: 2 * Hp + 2 * Wp - 2], B, L, H, Hp, Wp, 0.125)
     e_o, e_l = relerr(out.float(), ref), relerr(lse, lse_ref)
     assert e_l < (1e-5 if T == torch.float32 else 2e-3), (e_o, e_l)
-    assert e_o < (2e-5 if T == torch.float32 else 2e-2), (e_o, e_l)
+    assert e_o < (2e-5 if T == torch.float32 else 1.2e-2), (e_o, e_l)      # bf16: measured <= 7.8e-3 (tools/attn3_diag.py), the output's own rounding is 3.9e-3
 
 
 @pytest.mark.parametrize("gen_", [0, 5, 4, 2])
@@ -271,7 +271,7 @@ def test_attn_bwd(T, B, H, Hp, Wp, gen_, attn_generation):
     ref, _ = attn_reference(q64, rh64, rw64, B, L, H, Hp, Wp, 0.125)
     ref.backward(dout.double())
     D = H * 64
-    tol = 5e-5 if T == torch.float32 else 3e-2
+    tol = 5e-5 if T == torch.float32 else 1.6e-2       # bf16: measured <= 1.05e-2 of the largest entry (tools/attn3_diag.py)
     errs = dict(dq=relerr(dqkv[:, :D].float(), q64.grad[:, :D]), dk=relerr(dqkv[:, D:2 * D].float(), q64.grad[:, D:2 * D]),
                 dv=relerr(dqkv[:, 2 * D:].float(), q64.grad[:, 2 * D:]), drh=relerr(drcat[:nh], rh64.grad),
                 drw=relerr(drcat[nh:nh + nw], rw64.grad))
@@ -530,3 +530,42 @@ def test_gemm256_epilogues_bitstable_beside_concurrent_mfma_kernels():
     torch.cuda.synchronize()
     bad = _beside_mfma_load(once, ref, 125, 8)               # 1000 x 3 GEMM launches
     assert bad == 0, "%d of 1000 runs differ" % bad
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("seggpt", [False, True])
+def test_patch_embed_and_token_assembly_in_isolation(T, seggpt):
+    """pa_patch_embed_fwd / pa_patch_embed_wgrad alone: Conv2d(3, D, 16, 16) as an im2col GEMM with the token
+    assembly in its epilogue (util/vitdet_utils.py:182-186; models_painter.py:387-409: mask token on the masked target patches, segment
+    tokens, abs pos; models_seggpt.py:415-420: type tokens) against torch's conv2d in fp64, and the weight gradient against autograd."""
+    B, Hp, Wp, P, D = 2, 4, 6, 16, 128
+    L = Hp * Wp
+    imgs, tgts = gen((B, 3, Hp * P, Wp * P), 1), gen((B, 3, Hp * P, Wp * P), 2)
+    w, bias = gen((D, 3, P, P), 3, 0.05), gen((D,), 4, 0.1)
+    mask_token, seg_x, seg_y = gen((D,), 5, 0.3), gen((D,), 6, 0.3), gen((D,), 7, 0.3)
+    pos = gen((L, D), 8, 0.2)
+    tcls, tins = gen((D,), 9, 0.3), gen((D,), 10, 0.3)
+    seg_type = torch.tensor([0.0, 1.0], device=DEV)
+    mask = (torch.rand(B, L, generator=torch.Generator().manual_seed(11)) < 0.4).to(DEV)
+    wq = w.to(T)
+    x = ops.patch_embed_fwd(T, imgs, tgts, wq.reshape(D, -1).contiguous(), bias, mask_token, seg_x, seg_y, pos, mask.to(torch.uint8),
+                            tcls if seggpt else None, tins if seggpt else None, seg_type if seggpt else None, B, Hp, Wp, P, D)
+    conv = lambda im: torch.nn.functional.conv2d(im.to(T).double(), wq.double(), bias.double(), stride=P).permute(0, 2, 3, 1).reshape(B, L, D)
+    ex, ey = conv(imgs), conv(tgts)
+    m = mask.double()[:, :, None]
+    ey = ey * (1 - m) + mask_token.double() * m
+    ex, ey = ex + seg_x.double(), ey + seg_y.double()
+    ex, ey = ex + pos.double(), ey + pos.double()
+    if seggpt:
+        st = seg_type.double()[:, None, None]                       # models_seggpt.py:415-420: type 0 -> type_token_cls, type 1 -> type_token_ins
+        tt = tcls.double() * (st == 0) + tins.double() * (st == 1)
+        ex, ey = ex + tt, ey + tt
+    ref = torch.cat([ex, ey], 0).reshape(2 * B * L, D)
+    assert relerr(x, ref) < (2e-6 if T == torch.float32 else 3e-3), relerr(x, ref)
+    # weight gradient: dW[d, c, i, j] = sum over both streams and patches of dpe * pixel (masked target patches contribute nothing upstream:
+    # tokens_bwd zeroes them before this GEMM, here dpe is given)
+    dpe = gen((2 * B * L, D), 12, 1.0, T)
+    dw = ops.patch_embed_wgrad(dpe, imgs, tgts, B, Hp, Wp, P, D)
+    cols = lambda im: torch.nn.functional.unfold(im.to(T).double(), P, stride=P).transpose(1, 2).reshape(B * L, 3 * P * P)
+    refw = dpe.double()[:B * L].t() @ cols(imgs) + dpe.double()[B * L:].t() @ cols(tgts)
+    assert relerr(dw, refw) < (2e-6 if T == torch.float32 else 2e-5), relerr(dw, refw)
