@@ -190,7 +190,9 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
                                                           const bf16* __restrict__ dout, size_t lddo, const float* __restrict__ lse,
                                                           const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv,
                                                           bf16* __restrict__ dG, int L, int H, int Hp, int NRP, float scale, int nblk,
-                                                          int xcd_map) {
+                                                          int xcd_map, int abl) {
+    // abl (diagnostics, PA_ATTN3_DQ_ABL; results are WRONG with any bit set): 1 no r-space loop after the key loop, 2 no dG stores,
+    // 4 no dQ store, 16 no key loop
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, ql = lane & 31;
     const int trwg = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : -1);
@@ -215,6 +217,11 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     const int qh = q / WP, qw = q % WP;
     unsigned char* thT = smem + 2 * STAGE_QK + wave * Hp * 64;
     unsigned char* eimg = smem + 2 * STAGE_QK + NW * Hp * 64;
+    // Rcat^T [64 d][NRP] bf16, the A operand of the r-space step after the key loop, staged once per workgroup: fetching its fragments
+    // from global memory step by step made that short loop latency-bound (11 dependent L2 round trips; ablation: 33 us of the 213 us
+    // kernel at the ViT-L grid).  Row pitch NRP * 2 + 16 bytes keeps the 16-byte fragment reads of 32 rows off each other's banks.
+    unsigned char* rimg = eimg + PH * EIMG;
+    const int rpitch = NRP * 2 + 16;
     LaneAddr la;
     la.init(lane);
     EAddr ea;
@@ -224,6 +231,11 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     Stager ks, vs;
     ks.load(kbase, ldq, tid);
     vs.load(vbase, ldq, tid);
+    const int rchunks = ATT_HD * (NRP / 8);               // 16-byte chunks of Rcat^T
+    uint4 rch[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+        if (tid + NT * i < rchunks) rch[i] = *reinterpret_cast<const uint4*>(rcatT + (size_t)(tid + NT * i) * 8);
 
     // every global load of the prologue is in flight before the LDS work (one-hot images, table copy) starts
     bf16x8 qf[4], dof[4];
@@ -246,6 +258,16 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         ndlt = *reinterpret_cast<const float*>(tt + 2048 + (Hp + 2) * 64 + ql * 4);
     }
     build_eimg(eimg, tid);
+    {
+        const int per_row = NRP / 8;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = tid + NT * i;
+            if (c < rchunks) *reinterpret_cast<uint4*>(rimg + (c / per_row) * rpitch + (c % per_row) * 16) = rch[i];
+        }
+        for (int c = tid + NT * 6; c < rchunks; c += NT)
+            *reinterpret_cast<uint4*>(rimg + (c / per_row) * rpitch + (c % per_row) * 16) = *reinterpret_cast<const uint4*>(rcatT + (size_t)c * 8);
+    }
     if (valid) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -347,7 +369,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         __syncthreads();
         mark(6);
     };
-    for (int a = 0; a < Hp / RPP; ++a) {
+    for (int a = 0; a < ((abl & 16) ? 0 : Hp / RPP); ++a) {
         body(std::integral_constant<int, 0>{}, a);
         body(std::integral_constant<int, 1>{}, a);
         body(std::integral_constant<int, 2>{}, a);
@@ -405,16 +427,18 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             }
         };
         const int nstep = NRP / 16;
-        bf16x8 rf[2] = {gfrag(rcatT + (size_t)ql * NRP, 0, g), gfrag(rcatT + (size_t)(32 + ql) * NRP, 0, g)};
+        const unsigned char* r0 = rimg + ql * rpitch + 16 * g, *r1 = r0 + 32 * rpitch;
+        auto rfrag = [&](const unsigned char* rp, int s) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(rp + 32 * s)); };
+        bf16x8 rf[2] = {rfrag(r0, 0), rfrag(r1, 0)};
         float gcur[8];
         gather(0, gcur);
-        for (int s = 0; s < nstep; ++s) {
+        for (int s = 0; s < ((abl & 1) ? 0 : nstep); ++s) {
             const int sn = min(s + 1, nstep - 1);
-            const bf16x8 rn[2] = {gfrag(rcatT + (size_t)ql * NRP, sn, g), gfrag(rcatT + (size_t)(32 + ql) * NRP, sn, g)};
+            const bf16x8 rn[2] = {rfrag(r0, sn), rfrag(r1, sn)};
             float gnext[8];
             gather(sn, gnext);
             const bf16x8 gf = packfrag(gcur);
-            *reinterpret_cast<uint4*>(dgrow + 16 * s + 8 * g) = __builtin_bit_cast(uint4, gf);
+            if (!(abl & 2)) *reinterpret_cast<uint4*>(dgrow + 16 * s + 8 * g) = __builtin_bit_cast(uint4, gf);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 dq[db] = mfma(rf[db], gf, dq[db]);
@@ -424,7 +448,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             for (int t = 0; t < 8; ++t) gcur[t] = gnext[t];
         }
         stage_rows(stg, dq, 1.f, lane);
-        write_rows(stg, dqkv + (size_t)(b * L + qt * 32) * ldq + h * ATT_HD, ldq, lane);
+        if (!(abl & 4)) write_rows(stg, dqkv + (size_t)(b * L + qt * 32) * ldq + h * ATT_HD, ldq, lane);
     }
     if constexpr (TR) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     coarse(63);
@@ -690,12 +714,13 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
         if ((e = attn3s_dq(qkv, ldq, rcatT, dout, lddo, lse, tables, dqkv, dG, Bn, L, H, Hp, Wp, scale, st))) return e;
     } else {
         static const size_t pad = [] { const char* v = getenv("PA_ATTN3_LDS_PAD"); return v ? (size_t)atoi(v) : (size_t)0; }();   // diagnostics: fewer workgroups per CU
-        const size_t smem = 2 * (size_t)STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG + pad;
+        const size_t smem = 2 * (size_t)STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG + (size_t)ATT_HD * (NRP * 2 + 16) + pad;
         auto kern = g_attn_trace ? bwd_dq_kernel<2, true, true> : (dq_w == 3 ? bwd_dq_kernel<3, false> : bwd_dq_kernel<2, true>);
         static bool done2 = false, done3 = false, donet = false;
         if ((e = set_smem(reinterpret_cast<const void*>(kern), g_attn_trace ? donet : (dq_w == 3 ? done3 : done2)))) return e;
+        const char* ablv = getenv("PA_ATTN3_DQ_ABL");           // diagnostics, read per launch
         PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcatT, dout, (size_t)lddo, lse, tb, dqkv, dG, L, H, Hp,
-                  NRP, scale, nblk, a3_xcd_map_on());
+                  NRP, scale, nblk, a3_xcd_map_on(), ablv ? atoi(ablv) : 0);
         if ((e = (int)hipGetLastError())) return e;
     }
     {

@@ -200,7 +200,9 @@ __global__ __launch_bounds__(NTP, 2) void fwd_kernel(const bf16* __restrict__ qk
 __global__ __launch_bounds__(NTP, 2) void bwd_dq_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcatT,
                                                         const bf16* __restrict__ dout, size_t lddo, const float* __restrict__ lse,
                                                         const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv, bf16* __restrict__ dG,
-                                                        int L, int H, int Hp, int NRP, float scale, int nblk, int xcd_map) {
+                                                        int L, int H, int Hp, int NRP, float scale, int nblk, int xcd_map, int abl) {
+    // abl (diagnostics, PA_ATTN3_ABL; results are WRONG with any bit set): 1 no staging traffic, 4 no LDS fragment requests, 8 no exp / dS VALU,
+    // 16 no table write-backs, 32 no MFMAs, 128 no phase barriers
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, ql = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2, st = tid & 255;
@@ -291,17 +293,26 @@ __global__ __launch_bounds__(NTP, 2) void bwd_dq_kernel(const bf16* __restrict__
             const unsigned char* ei = eimg + P * EIMG;
             const unsigned char* eprev = eimg + PP * EIMG;
             bf16x8 ktr[2][2], etr[2], kfr[4], vfr[4];
+            bf16x8 ef0, ef1;
+            if (abl & 4) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) { kfr[s] = qf[s]; vfr[s] = dof[s]; }
+                ktr[0][0] = ktr[0][1] = ktr[1][0] = ktr[1][1] = etr[0] = etr[1] = ef0 = ef1 = qf[0];
+            } else {
             if (t > 0) {
 #pragma unroll
                 for (int db = 0; db < 2; ++db) { ktr[db][0] = trfrag(kprev, la, db, 0); ktr[db][1] = trfrag(kprev, la, db, 1); }
                 etr[0] = etrfrag(eprev, ea, 0);
                 etr[1] = etrfrag(eprev, ea, 1);
             }
-            const bf16x8 ef0 = efrag(ei, ea, 0), ef1 = efrag(ei, ea, 1);
+            ef0 = efrag(ei, ea, 0);
+            ef1 = efrag(ei, ea, 1);
 #pragma unroll
             for (int s = 0; s < 4; ++s) { vfr[s] = rowfrag(vimg, la, s); kfr[s] = rowfrag(kimg, la, s); }
+            }
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
+            if (!(abl & 32)) {
             if (t > 0) {
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
@@ -318,25 +329,33 @@ __global__ __launch_bounds__(NTP, 2) void bwd_dq_kernel(const bf16* __restrict__
             for (int s = 1; s < 4; ++s) dpacc = mfma(vfr[s], dof[s], dpacc);
 #pragma unroll
             for (int s = 0; s < 4; ++s) sacc = mfma(kfr[s], qf[s], sacc);
+            } else {
+                asm volatile("" : "+v"(kfr[0]), "+v"(vfr[0]), "+v"(ktr[0][0]), "+v"(etr[0]), "+v"(ef0), "+v"(ef1));
+                asm volatile("" : "+v"(kfr[1]), "+v"(vfr[1]), "+v"(ktr[0][1]), "+v"(etr[1]), "+v"(kfr[2]), "+v"(kfr[3]));
+                asm volatile("" : "+v"(vfr[2]), "+v"(vfr[3]), "+v"(ktr[1][0]), "+v"(ktr[1][1]));
+            }
             __builtin_amdgcn_s_setprio(0);
         }
-        phase_barrier();
+        if (!(abl & 128)) phase_barrier();
         // ---------------------------------------------------------------- V(t): write-back of tile t-1's completed key rows, staging, dS of tile t
-        if (valid && t > 0) {
+        if (valid && t > 0 && !(abl & 16)) {
             const int ap = P == 0 ? a - 1 : a;              // period of tile t-1
             write_back(PP & 3, ap * RPP + PP);
             if constexpr (PP == PH - 1) write_back((PP + 1) & 3, ap * RPP + PP + 1);
         }
         {
             const int tw = t + 1 + grp;
+            if (abl & 1) {
+            } else {
             if (tw < ntile) {
                 int sw = ring_next(slot);
                 if (grp) sw = ring_next(sw);
                 sg.store(ring + sw * STAGE_QK + soff, st);
             }
             sg.load(sbase + (size_t)min(tw + 1, ntile - 1) * 32 * ldq, ldq, st);
+            }
         }
-        if (valid) {
+        if (valid && !(abl & 8)) {
             float ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) ds[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], sl, nlse2)) * dpacc[r];
@@ -344,7 +363,7 @@ __global__ __launch_bounds__(NTP, 2) void bwd_dq_kernel(const bf16* __restrict__
             dsf1 = packfrag(ds + 8);
         }
         slot = ring_next(slot);
-        phase_barrier();
+        if (!(abl & 128)) phase_barrier();
     };
     for (int a = 0; a < Hp / RPP; ++a) { A3P_FOR_PHASES(body, a) }
     // tail: second MFMA group of the last tile (phase 6 of the last period), its two completed key rows
@@ -664,8 +683,10 @@ int attn3p_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout
         const size_t smem = (size_t)NWP * Hp * 64 + RING * STAGE_QK + PH * EIMG;
         static bool done = false;
         if ((e = set_smem(reinterpret_cast<const void*>(bwd_dq_kernel), done))) return e;
+        const char* ablv = getenv("PA_ATTN3_ABL");           // diagnostics, read per launch
+        const int abl = ablv ? atoi(ablv) : 0;
         PA_LAUNCH(bwd_dq_kernel, dim3(nblk * Bn * H), dim3(NTP), smem, st, qkv, (size_t)ldq, rcatT, dout, (size_t)lddo, lse, tb, dqkv, dG, L, H,
-                  Hp, NRP, scale, nblk, a3p_xcd_map_on());
+                  Hp, NRP, scale, nblk, a3p_xcd_map_on(), abl);
         if ((e = (int)hipGetLastError())) return e;
     }
     {

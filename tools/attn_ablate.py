@@ -34,10 +34,26 @@ def main():
     rel_w = (torch.randn(2 * Wp - 1, 64, generator=g) * 0.05).cuda()
     rcat = ops.relpos_pack(rel_h, rel_w, Hp, Wp, T)
     rcatT = ops.relpos_pack_t(rel_h, rel_w, Hp, Wp, T)
-    lib.pa_attn_set_generation(5)
+    paired = len(sys.argv) > 1 and sys.argv[1] == "paired"
+    if len(sys.argv) > 1 and sys.argv[1] == "epilogue":          # the default 4-wave dQ kernel: what is outside the key loop worth?
+        lib.pa_attn_set_generation(0)
+        out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
+        names = {1: "no r-space loop", 2: "no dG stores", 4: "no dQ store", 16: "no key loop"}
+        for _ in range(2):
+            for m in (0, 1, 2, 4, 7, 16, 16 + 1, 16 + 7, 0):
+                os.environ["PA_ATTN3_DQ_ABL"] = str(m)
+                t = timeit(lambda: ops.attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables))
+                print("abl %3d  dq+dkv %.3f ms   [%s]" % (m, t, ", ".join(v for k, v in names.items() if m & k) or "full kernel"), flush=True)
+        os.environ.pop("PA_ATTN3_DQ_ABL")
+        return
+    lib.pa_attn_set_generation(4 if paired else 5)
     out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
-    names = {1: "no staging", 2: "no barrier", 4: "no LDS frag loads", 8: "no exp", 16: "no write-back", 32: "no MFMA group 2", 64: "no MFMA group 1"}
-    masks = [0, 1, 3, 4, 7, 8, 16, 32, 64, 96, 96 + 8, 127, 0]
+    if paired:      # attn3p.hip's mask
+        names = {1: "no staging", 4: "no LDS frag loads", 8: "no exp / dS VALU", 16: "no write-back", 32: "no MFMAs", 128: "no phase barriers"}
+        masks = [0, 1, 4, 8, 16, 32, 128, 8 + 16, 32 + 4, 1 + 4 + 8 + 16 + 32, 255, 0]
+    else:
+        names = {1: "no staging", 2: "no barrier", 4: "no LDS frag loads", 8: "no exp", 16: "no write-back", 32: "no MFMA group 2", 64: "no MFMA group 1"}
+        masks = [0, 1, 3, 4, 7, 8, 16, 32, 64, 96, 96 + 8, 127, 0]
     for _ in range(2):
         for m in masks:
             os.environ["PA_ATTN3_ABL"] = str(m)
