@@ -146,6 +146,40 @@ DEVI float gelu_grad_fast(float x) {
     return fmaf(x * 0.39894228040143268f, e, c);
 }
 
+// Two elements at once for the gemm256 / gemm128 epilogues, where the GELU is 33 us of the 154 us fc1 launch with the matrix pipe idle
+// (tools/fc1_epilogue.py): the same A-S polynomial on float2 values -- hipcc emits v_pk_mul / v_pk_fma / v_pk_add_f32 for these, half
+// the issue slots of the scalar form -- with the constants folded (0.5 into the coefficients, 1/sqrt2 into the rcp argument) and the
+// sign handled by copysign instead of compare + select.  Packed fp32 arithmetic is bit-identical to scalar, alone and beside MFMA
+// kernels (tools/ubench); only rcp and exp2 stay per element.  Results equal gelu_fast / gelu_grad_fast up to the
+// association of the folded constants (1-2 ulp of fp32, far below the bf16 rounding that follows).
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+DEVI void gelu_parts2(f32x2_t x, f32x2_t& cdf, f32x2_t& e) {
+    const f32x2_t ax = {fabsf(x[0]), fabsf(x[1])};
+    const f32x2_t d = __builtin_elementwise_fma(ax, (f32x2_t){0.23164189f, 0.23164189f}, (f32x2_t){1.0f, 1.0f});      // 1 + 0.3275911 |x| / sqrt 2
+    const f32x2_t t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const f32x2_t xx = x * x * (f32x2_t){-0.72134752044448170f, -0.72134752044448170f};
+    e = (f32x2_t){__builtin_amdgcn_exp2f(xx[0]), __builtin_amdgcn_exp2f(xx[1])};                                     // exp(-x^2 / 2)
+    f32x2_t p = __builtin_elementwise_fma(t, (f32x2_t){0.5307027145f, 0.5307027145f}, (f32x2_t){-0.7265760135f, -0.7265760135f});   // 0.5 * A-S 7.1.26
+    p = __builtin_elementwise_fma(p, t, (f32x2_t){0.7107068705f, 0.7107068705f});
+    p = __builtin_elementwise_fma(p, t, (f32x2_t){-0.142248368f, -0.142248368f});
+    p = __builtin_elementwise_fma(p, t, (f32x2_t){0.127414796f, 0.127414796f});
+    const f32x2_t h = p * t * e;                                                                                  // 0.5 * erfc(|x| / sqrt 2)
+    const f32x2_t m = (f32x2_t){0.5f, 0.5f} - h;                                                                  // >= 0
+    cdf = (f32x2_t){__builtin_copysignf(m[0], x[0]), __builtin_copysignf(m[1], x[1])} + (f32x2_t){0.5f, 0.5f};
+}
+DEVI f32x2_t gelu_fast2(float x0, float x1) {
+    const f32x2_t x = {x0, x1};
+    f32x2_t c, e;
+    gelu_parts2(x, c, e);
+    return x * c;
+}
+DEVI f32x2_t gelu_grad_fast2(float x0, float x1) {
+    const f32x2_t x = {x0, x1};
+    f32x2_t c, e;
+    gelu_parts2(x, c, e);
+    return __builtin_elementwise_fma(x * (f32x2_t){0.39894228040143268f, 0.39894228040143268f}, e, c);
+}
+
 // 4x4 transpose of a register block: in[i] = 4 consecutive elements (along r) of contraction row i;
 // out[j] = the 4 contraction values of element r+j.
 DEVI void transpose4x4(const uint4 (&in)[4], uint4 (&out)[4]) {   // float

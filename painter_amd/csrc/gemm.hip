@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include "gemm_engine.h"
 #include "gemm256.h"
+#include "gemm128.h"
 #include "../../include/painter_hip.h"
 
 // ------------------------------------------------------------------------------- epilogues
@@ -79,7 +80,10 @@ DEVI void store8(float* p, float4 a, float4 b) {
     *reinterpret_cast<float4*>(p + 4) = b;
 }
 DEVI float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-DEVI float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+DEVI float4 add4(float4 a, float4 b) {       // two v_pk_add_f32 (packed fp32 is exact: common.h, gelu_parts2)
+    const f32x2_t l = (f32x2_t){a.x, a.y} + (f32x2_t){b.x, b.y}, h = (f32x2_t){a.z, a.w} + (f32x2_t){b.z, b.w};
+    return make_float4(l[0], l[1], h[0], h[1]);
+}
 DEVI void load8(const bf16* p, float4& a, float4& b) {
     const uint4 w = *reinterpret_cast<const uint4*>(p);
     a = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
@@ -115,9 +119,9 @@ struct Epi4BiasGelu {
         b = add4(b, c.b);
         const uint4 pk = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
         if (pre) *reinterpret_cast<uint4*>(pre + (size_t)i * ld + j) = pk;
-        store8(act + (size_t)i * ld + j,
-               make_float4(gelu_fast(bf16_lo(pk.x)), gelu_fast(bf16_hi(pk.x)), gelu_fast(bf16_lo(pk.y)), gelu_fast(bf16_hi(pk.y))),
-               make_float4(gelu_fast(bf16_lo(pk.z)), gelu_fast(bf16_hi(pk.z)), gelu_fast(bf16_lo(pk.w)), gelu_fast(bf16_hi(pk.w))));
+        const f32x2_t g0 = gelu_fast2(bf16_lo(pk.x), bf16_hi(pk.x)), g1 = gelu_fast2(bf16_lo(pk.y), bf16_hi(pk.y)),
+                      g2 = gelu_fast2(bf16_lo(pk.z), bf16_hi(pk.z)), g3 = gelu_fast2(bf16_lo(pk.w), bf16_hi(pk.w));
+        store8(act + (size_t)i * ld + j, make_float4(g0[0], g0[1], g1[0], g1[1]), make_float4(g2[0], g2[1], g3[0], g3[1]));
     }
 };
 struct Epi4BiasResid {
@@ -158,9 +162,9 @@ struct Epi4DGelu {
         const uint4 w = r.p;
         const float4 pa = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
         const float4 pb = make_float4(bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w));
-        store8(out + (size_t)i * ld + j,
-               make_float4(a.x * gelu_grad_fast(pa.x), a.y * gelu_grad_fast(pa.y), a.z * gelu_grad_fast(pa.z), a.w * gelu_grad_fast(pa.w)),
-               make_float4(b.x * gelu_grad_fast(pb.x), b.y * gelu_grad_fast(pb.y), b.z * gelu_grad_fast(pb.z), b.w * gelu_grad_fast(pb.w)));
+        const f32x2_t g0 = gelu_grad_fast2(pa.x, pa.y), g1 = gelu_grad_fast2(pa.z, pa.w), g2 = gelu_grad_fast2(pb.x, pb.y), g3 = gelu_grad_fast2(pb.z, pb.w);
+        store8(out + (size_t)i * ld + j, make_float4(a.x * g0[0], a.y * g0[1], a.z * g1[0], a.w * g1[1]),
+               make_float4(b.x * g2[0], b.y * g2[1], b.z * g3[0], b.w * g3[1]));
     }
 };
 struct Epi4PixShuf {
@@ -295,6 +299,22 @@ static int linear_fwd_t(int epi, const T* x, int64_t ldx, const T* w, const floa
                         int64_t ldo, const float* resid, const float* rowscale, int rps, int M, int N, int K,
                         hipStream_t st) {
     if constexpr (std::is_same<T, bf16>::value) {
+        // tile shape: g_dbg-free policy knob PA_GEMM128 (0 never, 1 always, default 2 = when the 256 x 256 tiling needs more than one round)
+        static const int use128 = [] { const char* v = getenv("PA_GEMM128"); return v ? atoi(v) : 0; }();
+        const int gmode = g256::g_dbg[4] > 0 ? g256::g_dbg[4] - 1 : use128;             // pa_debug_set(4, 1 + mode): A/B inside one process
+        const bool multi_round = (int64_t)((M + 255) / 256) * ((N + 255) / 256) > 256;
+        if ((gmode == 1 || (gmode == 2 && multi_round)) && g128::ok(M, N, K, ldx, K)) {
+            switch (epi) {
+            case PA_EPI_BIAS:
+                return g128::launch(x, ldx, w, K, Epi4Bias<bf16>{(bf16*)out, (size_t)ldo, bias, M, N}, M, N, K, st);
+            case PA_EPI_BIAS_F32:
+                return g128::launch(x, ldx, w, K, Epi4Bias<float>{(float*)out, (size_t)ldo, bias, M, N}, M, N, K, st);
+            case PA_EPI_BIAS_GELU:
+                return g128::launch(x, ldx, w, K, Epi4BiasGelu{(bf16*)out2, (bf16*)out, (size_t)ldo, bias, M, N}, M, N, K, st);
+            case PA_EPI_BIAS_RESID:
+                return g128::launch(x, ldx, w, K, Epi4BiasResid{(float*)out, resid, (size_t)ldo, bias, rowscale, rps, M, N}, M, N, K, st);
+            }
+        }
         if (g256::ok(M, N, K, false, false, ldx, K)) {
             switch (epi) {
             case PA_EPI_BIAS:
@@ -439,7 +459,7 @@ extern "C" int pa_linear_wgrad(int dtype, const void* dy, int64_t lddy, const vo
 
 extern "C" int pa_abi_version(void) { return 1; }
 extern "C" int pa_debug_set(int which, int value) {
-    if (which < 0 || which >= 4) return (int)hipErrorInvalidValue;
+    if (which < 0 || which >= 8) return (int)hipErrorInvalidValue;
     g256::g_dbg[which] = value;
     return 0;
 }

@@ -26,7 +26,7 @@ namespace g256 {
 constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
 constexpr int LDS_BYTES = 131072;
 // diagnostics (pa_debug_set): [0] first-round de-phasing in shader cycles, [1] drop epilogue stores, [2] 1 = plain row-major tile order, [3] wgrad workgroup target
-inline int g_dbg[4] = {0, 0, 0, 0};
+inline int g_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // [4] gemm128 policy override: 0 = PA_GEMM128 / default, 1 + mode otherwise
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
