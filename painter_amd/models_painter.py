@@ -251,17 +251,24 @@ class Painter(nn.Module):
         """timm 0.3.2 DropPath factors: floor(keep + U[0,1)) / keep per sample, independent for the two branches."""
         if not self.training:
             return None
+        # one uniform draw, one floor, one division for every block (was six tiny launches per block = ~140 per step in front of the
+        # forward): row 2 i + b of `s` = branch b of block i, 2 * batch wide (blocks after the stream merge use the first `batch`)
+        n = len(self.blocks)
+        probs = tuple(float(blk.drop_path_prob) for blk in self.blocks)
+        cached = getattr(self, "_drop_keep", None)
+        if cached is None or cached[0] != probs or cached[1].device != device:
+            keep = torch.tensor([1.0 - p for p in probs for _ in range(2)], dtype=torch.float32).clamp_min(1e-12)
+            cached = self._drop_keep = (probs, keep.to(device)[:, None])
+        keep_d = cached[1]
+        r = torch.rand((2 * n, 2 * batch), device=device, dtype=torch.float32)
+        s = torch.floor(r + keep_d) / keep_d
         out = []
         for i, blk in enumerate(self.blocks):
-            p = blk.drop_path_prob
-            bc = 2 * batch if i <= self._cfg.merge_idx else batch
-            if p <= 0.0:
+            if blk.drop_path_prob <= 0.0:
                 out.append((None, None))
             else:
-                keep = 1.0 - p
-                r = torch.rand((2, bc), device=device, dtype=torch.float32)
-                s = torch.floor(r + keep) / keep
-                out.append((s[0].contiguous(), s[1].contiguous()))
+                bc = 2 * batch if i <= self._cfg.merge_idx else batch
+                out.append((s[2 * i, :bc], s[2 * i + 1, :bc]))         # contiguous row prefixes: no copies
         return out
 
     def _run(self, imgs, tgts, bool_masked_pos, valid, seg_type=None, merge_between_batch=-1):
