@@ -203,3 +203,20 @@ def test_gradient_buffers_replaced_between_steps_are_picked_up():
         ref.step()
     for a, b in zip(ours_p, ref_p):
         assert torch.allclose(a.detach(), b.detach(), rtol=2e-6, atol=1e-7)
+
+
+def test_plain_step_after_a_gradscaler_step():
+    """torch's GradScaler.step() deletes `optimizer.grad_scale` / `found_inf` after its call; a later step without the scaler must
+    still work (class-level defaults), and must not re-use the scaler's factors."""
+    p = torch.nn.Parameter(torch.ones(257, device="cuda"))
+    q = torch.nn.Parameter(torch.ones(257, device="cuda"))
+    ours, ref = PO.AdamW([p], lr=1e-2), torch.optim.AdamW([q], lr=1e-2)
+    s1, s2 = torch.amp.GradScaler("cuda", init_scale=64.0), torch.amp.GradScaler("cuda", init_scale=64.0)
+    for par, opt, sc in ((p, ours, s1), (q, ref, s2)):
+        sc.scale((par * par).sum()).backward()
+        sc.step(opt)
+        sc.update()
+        opt.zero_grad()
+        (par * par * 3.0).sum().backward()
+        opt.step()                                               # no scaler
+    assert torch.allclose(p.detach(), q.detach(), rtol=2e-6, atol=1e-7)
