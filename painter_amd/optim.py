@@ -33,10 +33,8 @@ class _Groups(ctypes.Structure):
 
 class AdamW(torch.optim.Optimizer):
     _step_supports_amp_scaling = True        # torch GradScaler then hands grad_scale / found_inf over instead of unscaling itself
-    # class-level defaults: torch's GradScaler.step() sets these on the instance and DELETES them afterwards, so a later plain
-    # opt.step() must still find the names
-    grad_scale = None
-    found_inf = None
+    # no class-level `grad_scale` / `found_inf`: torch's GradScaler.step() multiplies `getattr(optimizer, "grad_scale", 1)` into its scale and
+    # deletes both attributes afterwards; step() reads them with getattr(..., None)
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         if lr < 0.0 or eps < 0.0 or not (0.0 <= betas[0] < 1.0) or not (0.0 <= betas[1] < 1.0) or weight_decay < 0.0:

@@ -569,3 +569,33 @@ def test_patch_embed_and_token_assembly_in_isolation(T, seggpt):
     cols = lambda im: torch.nn.functional.unfold(im.to(T).double(), P, stride=P).transpose(1, 2).reshape(B * L, 3 * P * P)
     refw = dpe.double()[:B * L].t() @ cols(imgs) + dpe.double()[B * L:].t() @ cols(tgts)
     assert relerr(dw, refw) < (2e-6 if T == torch.float32 else 2e-5), relerr(dw, refw)
+
+
+@pytest.mark.parametrize("M,N,K", [(3136, 3072, 1024), (1000, 1024, 4096), (130, 264, 96), (12544, 4096, 1024)])
+def test_gemm128_forward_is_bit_identical_to_gemm256(M, N, K):
+    """The opt-in 128 x 256 / two-workgroups-per-CU forward kernel (csrc/gemm128.h) accumulates the same 16-deep MFMA steps in the same
+    order as gemm256: every fused forward epilogue must return the same bits, ragged edges included (where gemm256 does not take the shape,
+    both sides are compared with the fp64 product instead)."""
+    from painter_amd._lib import lib
+    T = torch.bfloat16
+    x, w, b = gen((M, K), 1, 1.0, T), gen((N, K), 2, 0.05, T), gen((N,), 3)
+    resid = gen((M, N), 4)
+
+    def run():
+        act, pre = ops.linear_gelu(x, w, b)
+        return (ops.linear_fwd(x, w, b, EPI_BIAS), ops.linear_fwd(x, w, b, EPI_BIAS_F32), act, pre,
+                ops.linear_fwd(x, w, b, EPI_BIAS_RESID, resid=resid))
+
+    try:
+        lib.pa_debug_set(4, 1)          # gemm256 / generic engine
+        ref = run()
+        lib.pa_debug_set(4, 2)          # gemm128 wherever it takes the shape
+        got = run()
+    finally:
+        lib.pa_debug_set(4, 0)
+    if K % 128 == 0 and M >= 8:         # gemm256's own fast path took it: bits must agree
+        for a, r in zip(got, ref):
+            assert torch.equal(a, r)
+    exact = x.double() @ w.double().t() + b.double()
+    assert relerr(got[1], exact) < 5e-6 * (K ** 0.5)
+    assert relerr(got[4], exact + resid.double()) < 5e-6 * (K ** 0.5)
