@@ -297,3 +297,44 @@ def test_three_training_steps_match_cpu_reference_loop():
         assert abs(loss.item() - lo.item()) <= 2e-4 * abs(lo.item()), (it, loss.item(), lo.item())
     worst = max(float((p.detach().cpu() - Pc[n].detach()).abs().max() / Pc[n].detach().abs().max().clamp_min(1e-6)) for n, p in m.named_parameters())
     assert worst < 1e-3, worst
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_two_forwards_before_one_backward_and_interleaved_modules(dtype):
+    """Autograd bookkeeping of the one-node forward/backward: two forward passes (different inputs) whose losses are summed and
+    differentiated once, with a SECOND module's forward + backward run in between, must give the sum of the separately computed
+    gradients -- nothing of a call's saved state may live in scratch that a later call reuses.  fp32 build: to rounding; bf16 build:
+    bit for bit (same kernels, same order per call)."""
+    cfg = O.small_config()
+    m, _ = build(cfg, 31, dtype)
+    other, _ = build(cfg, 32, dtype)
+    batches = [O.synthetic_batch(cfg, 2, 70 + k, "random") for k in range(3)]
+
+    def fwd(mod, k):
+        imgs, tgts, mask, valid = batches[k]
+        return mod(imgs.cuda(), tgts.cuda(), bool_masked_pos=mask.reshape(2, *cfg.grid).cuda(), valid=valid.cuda())[0]
+
+    def grads(mod):
+        return [p.grad.detach().clone() for p in mod.parameters()]
+
+    sep = []
+    for k in (0, 1):
+        for p in m.parameters():
+            p.grad = None
+        fwd(m, k).backward()
+        sep.append(grads(m))
+    for p in m.parameters():
+        p.grad = None
+    l0 = fwd(m, 0)
+    lo = fwd(other, 2)                      # another module's whole step between our two forwards
+    lo.backward()
+    l1 = fwd(m, 1)
+    (l0 + l1).backward()
+    torch.cuda.synchronize()
+    for g, a, b in zip(grads(m), sep[0], sep[1]):
+        ref = a + b
+        if dtype == "bf16":
+            assert torch.equal(g, ref)
+        else:
+            assert float((g - ref).abs().max()) <= 1e-6 * float(ref.abs().max().clamp_min(1e-12)) + 1e-12
+    assert all(p.grad is not None for p in other.parameters())
