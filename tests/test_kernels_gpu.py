@@ -599,3 +599,22 @@ def test_gemm128_forward_is_bit_identical_to_gemm256(M, N, K):
     exact = x.double() @ w.double().t() + b.double()
     assert relerr(got[1], exact) < 5e-6 * (K ** 0.5)
     assert relerr(got[4], exact + resid.double()) < 5e-6 * (K ** 0.5)
+
+
+def test_c_abi_of_the_hot_path_rejects_bad_shapes_instead_of_reading_out_of_bounds():
+    """Error behaviour at the boundary: every entry point returns a hipError (the Python binding raises) for a shape its kernels cannot
+    take -- contraction not a multiple of the vector width, token count that is not Hp x Wp, feature width not a multiple of 4, odd debug
+    knobs -- rather than launching."""
+    from painter_amd._lib import PA_BF16, PA_F32, lib
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device=DEV)
+    p_, s = buf.data_ptr(), torch.cuda.current_stream().cuda_stream
+    assert lib.pa_linear_fwd(PA_BF16, 0, p_, 12, p_, p_, p_, None, 16, None, None, 1, 4, 16, 12, s) != 0           # K % 8
+    assert lib.pa_linear_fwd(PA_F32, 0, p_, 6, p_, p_, p_, None, 16, None, None, 1, 4, 16, 6, s) != 0              # K % 4
+    assert lib.pa_attn_fwd(PA_BF16, p_, 192, p_, p_, 64, p_, None, 1, 100, 1, 8, 12, 0.125, s) != 0                 # L != Hp * Wp
+    assert lib.pa_attn_fwd(PA_BF16, p_, 192, p_, p_, 64, p_, None, 1, 90, 1, 9, 10, 0.125, s) != 0                  # grid not a multiple of 4
+    assert lib.pa_layernorm_fwd(PA_BF16, p_, 6, p_, p_, 1e-6, p_, 6, p_, p_, 4, 6, s) != 0                          # D % 4
+    assert lib.pa_debug_set(99, 1) != 0
+    assert lib.pa_attn_set_generation(7) != 0
+    with pytest.raises(RuntimeError):
+        ops.linear_fwd(torch.zeros(4, 12, dtype=torch.bfloat16, device=DEV), torch.zeros(16, 12, dtype=torch.bfloat16, device=DEV), torch.zeros(16, device=DEV))
+    torch.cuda.synchronize()

@@ -150,3 +150,20 @@ def test_gradsync_world2_model_gradients_with_accumulation():
         worst_big = max(worst_big, float((g0[n] - bigb).abs().max() / bigb.abs().max().clamp_min(1e-12)))
     assert worst_mean < 1e-6, worst_mean
     assert worst_big < 1e-4, worst_big                       # only the `+ 1e-2` in the loss denominator separates the two
+
+
+def test_bench_refuses_a_line_for_fewer_gpus_than_asked(tmp_path):
+    """bench.py --gpus N (N > 1): without a launcher and without N devices it exits with a message instead of running on one GPU; under a
+    launcher it refuses a WORLD_SIZE that differs from --gpus.  Either way no JSON line is printed."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout) and "{" not in r.stdout
+    env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout) and "{" not in r.stdout
