@@ -89,6 +89,8 @@ int pa_attn_set_generation(int generation);
 /* diagnostics: enable != 0 runs the generation-3 dQ kernel with s_memtime stamps (two workgroups, waves 0 / 1, 64 tiles, 8 slots);
  * host_out (may be NULL) receives the 2 x 2 x 64 x 8 stamps of the last traced launch */
 int pa_attn_trace(int enable, unsigned long long* host_out);
+/* diagnostics: s_memtime stamps of the paired dQ kernel, 2 x 64 values (PA_ATTN3_ABL bit 512; csrc/attn3p.hip) */
+int pa_attn_trace_paired(unsigned long long* host_out);
 int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse,
                 void* tables, int batch, int L, int heads, int Hp, int Wp, float scale, hipStream_t stream);
 

@@ -197,6 +197,10 @@ __global__ __launch_bounds__(NTP, 2) void fwd_kernel(const bf16* __restrict__ qk
 
 // =============================================================================================== backward: dQ, bias gradients
 // LDS: thT 8 waves x [Hp][32 q] bf16 (values, replaced row by row by their gradients) | ring 3 x [K img | V img] | 7 one-hot images
+// diagnostics (PA_ATTN3_ABL bit 512): s_memtime stamps of workgroup 0, waves 0 (group 0) and 4 (group 1): [wave][0] kernel start, [1] loop
+// start, [2] loop end, [3] kernel end, [8 + 4 t + k], t < 12: tile t's phase marks k = 0 top of M, 1 after M's MFMAs were issued, 2 after the
+// barrier that ends M, 3 after V's work (before its barrier)
+__device__ unsigned long long g_trace_p[2][64];
 __global__ __launch_bounds__(NTP, 2) void bwd_dq_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcatT,
                                                         const bf16* __restrict__ dout, size_t lddo, const float* __restrict__ lse,
                                                         const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv, bf16* __restrict__ dG,
@@ -206,6 +210,16 @@ __global__ __launch_bounds__(NTP, 2) void bwd_dq_kernel(const bf16* __restrict__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, g = lane >> 5, ql = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), grp = wave >> 2, st = tid & 255;
+    const bool trace = (abl & 512) && blockIdx.x == 0 && (wave & 3) == 0;
+    auto stamp = [&](int slot) {
+        if (trace) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && slot < 64) g_trace_p[grp][slot] = t;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    stamp(0);
     int blk, bh;
     wg_coords(nblk, xcd_map, blk, bh);
     const int b = bh / H, h = bh % H, D = H * ATT_HD;
@@ -277,10 +291,12 @@ __global__ __launch_bounds__(NTP, 2) void bwd_dq_kernel(const bf16* __restrict__
         }
     };
 
+    stamp(1);
     auto body = [&](auto pc, int a) {
         constexpr int P = decltype(pc)::value;
         constexpr int PP = (P + PH - 1) % PH;               // phase of tile t-1
         const int t = a * PH + P;
+        if (t < 12) stamp(8 + 4 * t);
         const int sprev = slot == 0 ? RING - 1 : slot - 1;
         // ---------------------------------------------------------------- M(t): dQ / bias-gradient MFMAs of tile t-1, S and dP of tile t
         if (valid) {
@@ -336,7 +352,9 @@ __global__ __launch_bounds__(NTP, 2) void bwd_dq_kernel(const bf16* __restrict__
             }
             __builtin_amdgcn_s_setprio(0);
         }
+        if (t < 12) stamp(9 + 4 * t);
         if (!(abl & 128)) phase_barrier();
+        if (t < 12) stamp(10 + 4 * t);
         // ---------------------------------------------------------------- V(t): write-back of tile t-1's completed key rows, staging, dS of tile t
         if (valid && t > 0 && !(abl & 16)) {
             const int ap = P == 0 ? a - 1 : a;              // period of tile t-1
@@ -363,9 +381,11 @@ __global__ __launch_bounds__(NTP, 2) void bwd_dq_kernel(const bf16* __restrict__
             dsf1 = packfrag(ds + 8);
         }
         slot = ring_next(slot);
+        if (t < 12) stamp(11 + 4 * t);
         if (!(abl & 128)) phase_barrier();
     };
     for (int a = 0; a < Hp / RPP; ++a) { A3P_FOR_PHASES(body, a) }
+    stamp(2);
     // tail: second MFMA group of the last tile (phase 6 of the last period), its two completed key rows
     if (valid) {
         const unsigned char* kprev = ring + (slot == 0 ? RING - 1 : slot - 1) * STAGE_QK;
@@ -428,6 +448,8 @@ __global__ __launch_bounds__(NTP, 2) void bwd_dq_kernel(const bf16* __restrict__
         stage_rows(mine, dq, 1.f, lane);                    // same-wave LDS ops are ordered: the gather above is complete
         write_rows(mine, dqkv + (size_t)(b * L + qt * 32) * ldq + h * ATT_HD, ldq, lane);
     }
+    if (trace) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp(3);
 }
 
 // =============================================================================================== backward: dK, dV
@@ -646,6 +668,10 @@ __global__ __launch_bounds__(NTP, 2) void bwd_dkv_kernel(const bf16* __restrict_
 
 }   // namespace pr
 }   // namespace a3
+
+extern "C" int pa_attn_trace_paired(unsigned long long* host_out) {
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(a3::pr::g_trace_p), sizeof(a3::pr::g_trace_p));
+}
 
 static int a3p_xcd_map_on() {
     static const int v = [] { const char* e = getenv("PA_ATTN_XCD"); return e ? atoi(e) : 1; }();
