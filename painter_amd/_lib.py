@@ -7,7 +7,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "painter_hip.h")
-LIB_PATH = os.path.join(HERE, "lib", "libpainter_hip.so")
+LIB_PATH = os.environ.get("PAINTER_AMD_LIB") or os.path.join(HERE, "lib", "libpainter_hip.so")      # PAINTER_AMD_LIB: A/B builds (diagnostics)
 
 PA_F32, PA_BF16 = 0, 1
 EPI_BIAS, EPI_BIAS_F32, EPI_BIAS_GELU, EPI_BIAS_RESID = 0, 1, 2, 3

@@ -35,6 +35,13 @@
 #include "attn3.h"
 #include <cstdlib>
 
+#ifndef A3_PRIO
+#define A3_PRIO 0
+#endif
+// A3_PRIO = 1: raise the wave priority while it issues an MFMA group (experiment)
+#define A3_PRIO_UP() do { if (A3_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
+#define A3_PRIO_DOWN() do { if (A3_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
+
 namespace a3 {
 
 // =============================================================================================== forward
@@ -118,10 +125,12 @@ __global__ __launch_bounds__(NT, STAGES == 1 ? 4 : 2) void fwd_kernel(const bf16
             for (int s = 0; s < 4; ++s) kfr[s] = rowfrag(kimg, la, s);
             __builtin_amdgcn_sched_barrier(0);
             f32x16 sacc = zero16();
+            A3_PRIO_UP();
             sacc = mfma(ef0, as_frag(T0), sacc);
             sacc = mfma(ef1, as_frag(T1), sacc);
 #pragma unroll
             for (int s = 0; s < 4; ++s) sacc = mfma(kfr[s], qf[s], sacc);
+            A3_PRIO_DOWN();
             // V fragments travel while the softmax runs on the VALU (the 128-register single-stage build has room for half of them)
             bf16x8 vtr[2][2];
             vtr[0][0] = trfrag(vimg, la, 0, 0);
@@ -147,11 +156,13 @@ __global__ __launch_bounds__(NT, STAGES == 1 ? 4 : 2) void fwd_kernel(const bf16
             l += sum16(p);
             const bf16x8 pf0 = packfrag(p), pf1 = packfrag(p + 8);
             if constexpr (STAGES == 1) { vtr[1][0] = trfrag(vimg, la, 1, 0); vtr[1][1] = trfrag(vimg, la, 1, 1); }
+            A3_PRIO_UP();
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 oacc[db] = mfma(vtr[db][0], pf0, oacc[db]);
                 oacc[db] = mfma(vtr[db][1], pf1, oacc[db]);
             }
+            A3_PRIO_DOWN();
         }
         if constexpr (STAGES == 1) __syncthreads();      // every wave has finished reading the only stage
         if (j + 1 < ntile) {
@@ -320,6 +331,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             if constexpr (TR) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
             mark(1);
             f32x16 sacc = zero16(), dpacc;
+            A3_PRIO_UP();
             sacc = mfma(ef0, as_frag(T0), sacc);
             dpacc = mfma(vfr[0], dof[0], ndl);
             sacc = mfma(ef1, as_frag(T1), sacc);
@@ -327,6 +339,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             for (int s = 1; s < 4; ++s) dpacc = mfma(vfr[s], dof[s], dpacc);
 #pragma unroll
             for (int s = 0; s < 4; ++s) sacc = mfma(kfr[s], qf[s], sacc);
+            A3_PRIO_DOWN();
             // the transposed fragments of the second MFMA group travel while the VALU turns S, dP into dS
             bf16x8 ktr[2][2], etr[2];
 #pragma unroll
@@ -343,6 +356,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             }
             const bf16x8 dsf0 = packfrag(ds), dsf1 = packfrag(ds + 8);
             mark(3);
+            A3_PRIO_UP();
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 dq[db] = mfma(ktr[db][0], dsf0, dq[db]);
@@ -350,6 +364,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             }
             eacc = mfma(etr[0], dsf0, eacc);
             eacc = mfma(etr[1], dsf1, eacc);
+            A3_PRIO_DOWN();
             // key row 8 a + P is complete: its gradient (window slot P & 3 = a D row of half-wave 1) replaces the table entry
             if (g) {
                 *reinterpret_cast<bf16*>(thr + P * 64) = (bf16)eacc[win_reg(P & 3)];
@@ -581,6 +596,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
             if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);
             a1.w = wlo | (whi << 16);
             f32x16 sacc = zero16();
+            A3_PRIO_UP();
             sacc = mfma(as_frag(a0), eb0, sacc);                          // S[q][key] - lse: lane = key, registers = q rows
             sacc = mfma(as_frag(a1), eb1, sacc);
 #pragma unroll
@@ -588,6 +604,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
                 sacc = mfma(qfr[s], kf[s], sacc);
                 dpacc = mfma(dofr[s], vf[s], dpacc);                      // dP[q][key] - Delta[q]
             }
+            A3_PRIO_DOWN();
             bf16x8 dotr[2][2], qtr[2][2];
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
@@ -602,6 +619,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
                 ds[r] = p[r] * dpacc[r];
             }
             const bf16x8 pf0 = packfrag(p), pf1 = packfrag(p + 8), dsf0 = packfrag(ds), dsf1 = packfrag(ds + 8);
+            A3_PRIO_UP();
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 dv[db] = mfma(dotr[db][0], pf0, dv[db]);    // dV^T[d][key] += dO^T[d][q] P[q][key]
@@ -609,6 +627,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
                 dk[db] = mfma(qtr[db][0], dsf0, dk[db]);    // dK^T[d][key] += Q^T[d][q] dS[q][key]
                 dk[db] = mfma(qtr[db][1], dsf1, dk[db]);
             }
+            A3_PRIO_DOWN();
         }
         if (j + 1 < ntile) store_all((j + 1) & 1);
         __syncthreads();
