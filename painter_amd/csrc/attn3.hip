@@ -38,6 +38,12 @@
 #ifndef A3_PRIO
 #define A3_PRIO 0
 #endif
+#ifndef A3_HOIST
+#define A3_HOIST 1      // 0: no sched_barriers around the hoisted fragment loads of the backward kernels (experiment)
+#endif
+#ifndef A3_NDL
+#define A3_NDL true    // false: -Delta added on the VALU instead of riding in the dP accumulator init (experiment)
+#endif
 // A3_PRIO = 1: raise the wave priority while it issues an MFMA group (experiment)
 #define A3_PRIO_UP() do { if (A3_PRIO) __builtin_amdgcn_s_setprio(1); } while (0)
 #define A3_PRIO_DOWN() do { if (A3_PRIO) __builtin_amdgcn_s_setprio(0); } while (0)
@@ -209,10 +215,10 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     const int trwg = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : -1);
     auto coarse = [&](int pt) {          // traced build: stamps 60 kernel start, 61 loop start, 62 loop end, 63 kernel end (slot 0 of each)
         if constexpr (TR) {
-            if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
+            if constexpr (MINW < 3 && A3_HOIST) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             if (trwg >= 0 && wave < 2 && lane == 0) g_trace[((trwg * 2 + wave) * 64 + pt) * 8] = t;
-            if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
+            if constexpr (MINW < 3 && A3_HOIST) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
         }
     };
     coarse(60);
@@ -243,10 +249,6 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     ks.load(kbase, ldq, tid);
     vs.load(vbase, ldq, tid);
     const int rchunks = ATT_HD * (NRP / 8);               // 16-byte chunks of Rcat^T
-    uint4 rch[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-        if (tid + NT * i < rchunks) rch[i] = *reinterpret_cast<const uint4*>(rcatT + (size_t)(tid + NT * i) * 8);
 
     // every global load of the prologue is in flight before the LDS work (one-hot images, table copy) starts
     bf16x8 qf[4], dof[4];
@@ -269,15 +271,15 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         ndlt = *reinterpret_cast<const float*>(tt + 2048 + (Hp + 2) * 64 + ql * 4);
     }
     build_eimg(eimg, tid);
-    {
+    {   // 22 KB from L2, two chunks in flight per thread (held in registers across the prologue it made the kernel spill)
         const int per_row = NRP / 8;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const int c = tid + NT * i;
-            if (c < rchunks) *reinterpret_cast<uint4*>(rimg + (c / per_row) * rpitch + (c % per_row) * 16) = rch[i];
+        for (int c = tid; c < rchunks; c += 2 * NT) {
+            const int c2 = c + NT;
+            const uint4 v0 = *reinterpret_cast<const uint4*>(rcatT + (size_t)c * 8);
+            const uint4 v1 = c2 < rchunks ? *reinterpret_cast<const uint4*>(rcatT + (size_t)c2 * 8) : zero4();
+            *reinterpret_cast<uint4*>(rimg + (c / per_row) * rpitch + (c % per_row) * 16) = v0;
+            if (c2 < rchunks) *reinterpret_cast<uint4*>(rimg + (c2 / per_row) * rpitch + (c2 % per_row) * 16) = v1;
         }
-        for (int c = tid + NT * 6; c < rchunks; c += NT)
-            *reinterpret_cast<uint4*>(rimg + (c / per_row) * rpitch + (c % per_row) * 16) = *reinterpret_cast<const uint4*>(rcatT + (size_t)c * 8);
     }
     if (valid) {
 #pragma unroll
@@ -304,10 +306,10 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         const int j = a * PH + P;
         auto mark = [&](int pt) {
             if constexpr (TR) {
-                if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
+                if constexpr (MINW < 3 && A3_HOIST) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
                 const unsigned long long t = __builtin_amdgcn_s_memtime();
                 if (trwg >= 0 && wave < 2 && lane == 0 && j < 60) g_trace[((trwg * 2 + wave) * 64 + j) * 8 + pt] = t;
-                if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
+                if constexpr (MINW < 3 && A3_HOIST) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
             }
         };
         mark(0);
@@ -327,7 +329,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             bf16x8 kfr[4], vfr[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) { vfr[s] = rowfrag(vimg, la, s); kfr[s] = rowfrag(kimg, la, s); }
-            if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
+            if constexpr (MINW < 3 && A3_HOIST) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
             if constexpr (TR) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
             mark(1);
             f32x16 sacc = zero16(), dpacc;
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             for (int db = 0; db < 2; ++db) { ktr[db][0] = trfrag(kimg, la, db, 0); ktr[db][1] = trfrag(kimg, la, db, 1); }
             etr[0] = etrfrag(ei, ea, 0);
             etr[1] = etrfrag(ei, ea, 1);
-            if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
+            if constexpr (MINW < 3 && A3_HOIST) __builtin_amdgcn_sched_barrier(0);      // the 3-wave build leaves the order to the scheduler (register budget 168)
             mark(2);
             float ds[16];
 #pragma unroll
@@ -593,7 +595,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
             bf16x8 qfr[4], dofr[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) { qfr[s] = rowfrag(qimg, la, s); dofr[s] = rowfrag(doimg, la, s); }
-            if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MINW < 3 && A3_HOIST) __builtin_amdgcn_sched_barrier(0);
             a1.w = wlo | (whi << 16);
             f32x16 sacc = zero16();
             A3_PRIO_UP();
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
                 dotr[db][0] = trfrag(doimg, la, db, 0); dotr[db][1] = trfrag(doimg, la, db, 1);
                 qtr[db][0] = trfrag(qimg, la, db, 0); qtr[db][1] = trfrag(qimg, la, db, 1);
             }
-            if constexpr (MINW < 3) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MINW < 3 && A3_HOIST) __builtin_amdgcn_sched_barrier(0);
             float p[16], ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -734,7 +736,7 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
     } else {
         static const size_t pad = [] { const char* v = getenv("PA_ATTN3_LDS_PAD"); return v ? (size_t)atoi(v) : (size_t)0; }();   // diagnostics: fewer workgroups per CU
         const size_t smem = 2 * (size_t)STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG + (size_t)ATT_HD * (NRP * 2 + 16) + pad;
-        auto kern = g_attn_trace ? bwd_dq_kernel<2, true, true> : (dq_w == 3 ? bwd_dq_kernel<3, false> : bwd_dq_kernel<2, true>);
+        auto kern = g_attn_trace ? bwd_dq_kernel<2, true, true> : (dq_w == 3 ? bwd_dq_kernel<3, false> : bwd_dq_kernel<2, A3_NDL>);
         static bool done2 = false, done3 = false, donet = false;
         if ((e = set_smem(reinterpret_cast<const void*>(kern), g_attn_trace ? donet : (dq_w == 3 ? done3 : done2)))) return e;
         const char* ablv = getenv("PA_ATTN3_DQ_ABL");           // diagnostics, read per launch
