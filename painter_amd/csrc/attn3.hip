@@ -56,7 +56,8 @@ template <int STAGES>
 __global__ __launch_bounds__(NT, STAGES == 1 ? 4 : 2) void fwd_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcat,
                                                                       bf16* __restrict__ out, size_t ldo, float* __restrict__ lse,
                                                                       unsigned char* __restrict__ tables, int L, int H, int Hp, int NRP,
-                                                                      float scale, int nblk, int xcd_map) {
+                                                                      float scale, int nblk, int xcd_map, int abl) {
+    // abl (diagnostics, PA_ATTN3_FWD_ABL; results WRONG when set): 16 no key loop, 32 no table build in the prologue
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, ql = lane & 31;
     int blk, bh;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(NT, STAGES == 1 ? 4 : 2) void fwd_kernel(const bf16
     if (valid) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = gfrag(base + (size_t)q * ldq, s, g);
-        build_tables3(twimg, thT, rcat, NRP, qf, q / WP, q % WP, Hp, 1.f / scale, lane);
+        if (!(abl & 32)) build_tables3(twimg, thT, rcat, NRP, qf, q / WP, q % WP, Hp, 1.f / scale, lane, smem + tid * 2);      // trash: the K/V stage, still unused
         T0 = *reinterpret_cast<const uint4*>(twimg + ql * 64 + 16 * g);          // same-wave LDS ops are ordered
         T1 = *reinterpret_cast<const uint4*>(twimg + ql * 64 + 32 + 16 * g);
         if (tables != nullptr) {
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(NT, STAGES == 1 ? 4 : 2) void fwd_kernel(const bf16
         }
         __syncthreads();
     };
-    for (int a = 0; a < Hp / RPP; ++a) {
+    for (int a = 0; a < ((abl & 16) ? 0 : Hp / RPP); ++a) {
         body(std::integral_constant<int, 0>{}, a);
         body(std::integral_constant<int, 1>{}, a);
         body(std::integral_constant<int, 2>{}, a);
@@ -478,7 +479,8 @@ constexpr int DKV_TW = 2 * IMG, DKV_TH = DKV_TW + 2048, DKV_ND = DKV_TH + 512, D
 template <int MINW>
 __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ dout,
                                                            size_t lddo, const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv,
-                                                           int L, int H, int Hp, float scale, int nblk, int xcd_map) {
+                                                           int L, int H, int Hp, float scale, int nblk, int xcd_map, int abl) {
+    // abl (diagnostics, PA_ATTN3_DKV_ABL; results WRONG when set): 16 no query loop
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, ql = lane & 31;
     int blk, bh;
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
     f32x16 dk[2], dv[2];
     dk[0] = zero16(); dk[1] = zero16(); dv[0] = zero16(); dv[1] = zero16();
 
-    for (int j = 0; j < ntile; ++j) {
+    for (int j = 0; j < ((abl & 16) ? 0 : ntile); ++j) {
         if (j + 1 < ntile) load_all(j + 1);
         const unsigned char* qimg = smem + (j & 1) * DKV_STAGE;
         const unsigned char* doimg = qimg + IMG;
@@ -711,7 +713,7 @@ int attn3_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t
     if (int e = set_smem(reinterpret_cast<const void*>(kern), stages == 2 ? done2 : done1)) return e;
     const int nblk = (L / 32 + NW - 1) / NW;
     PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcat, out, (size_t)ldo, lse,
-              reinterpret_cast<unsigned char*>(tables), L, H, Hp, NRP, scale, nblk, a3_xcd_map_on());
+              reinterpret_cast<unsigned char*>(tables), L, H, Hp, NRP, scale, nblk, a3_xcd_map_on(), [] { const char* v = getenv("PA_ATTN3_FWD_ABL"); return v ? atoi(v) : 0; }());
     return (int)hipGetLastError();
 }
 
@@ -753,7 +755,7 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
         static bool done2 = false, done3 = false;
         if ((e = set_smem(reinterpret_cast<const void*>(kern), dkv_w == 3 ? done3 : done2))) return e;
         PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, dout, (size_t)lddo, tb, dqkv, L, H, Hp, scale, nblk,
-                  a3_xcd_map_on());
+                  a3_xcd_map_on(), [] { const char* v = getenv("PA_ATTN3_DKV_ABL"); return v ? atoi(v) : 0; }());
         return (int)hipGetLastError();
     }
 }

@@ -74,26 +74,40 @@ DEVI constexpr int win_reg(int slot) { return slot == 0 ? 10 : slot == 1 ? 11 : 
 // T of this lane's query row from G^T = Rcat . Q^T: kw part -> twimg[q][32 slots] (bf16, window slots stay zero),
 // kh part -> thT[kh][q] (bf16).  Both scaled by 1 / scale, so that logits = scale * log2e * (q.k + T.E).
 DEVI void build_tables3(unsigned char* twimg, unsigned char* thT, const bf16* rcat, int NRP, const bf16x8 (&qf)[4], int qh, int qw, int Hp,
-                        float inv_scale, int lane) {
+                        float inv_scale, int lane, unsigned char* trash) {
+    // The scatter of G^T's D tile into the two tables is straight-line code: per accumulator register one convert, one range test, one
+    // select between the entry's address and this lane's `trash` halfword (2 bytes per lane of LDS nobody reads), one ds_write_b16.
+    // With a branch per element the table build was 30 us of the 145 us forward launch at the ViT-L grid (ablation, tools/attn_ablate.py).
     const int g = lane >> 5, ql = lane & 31;
     *reinterpret_cast<uint4*>(twimg + lane * 32) = zero4();
     *reinterpret_cast<uint4*>(twimg + lane * 32 + 16) = zero4();
+    const int nkh = 2 * Hp - 1;
+    unsigned char* const th0 = thT + ql * 2;
+    unsigned char* const tw0 = twimg + ql * 64;
     for (int rbk = 0; rbk < NRP / 32; ++rbk) {
         f32x16 acc = zero16();
         const bf16* rp = rcat + (size_t)(rbk * 32 + ql) * ATT_HD;
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = mfma(gfrag(rp, s, g), qf[s], acc);
+        const int r0 = rbk * 32 + 4 * g;                            // r of register 0; register reg adds (reg & 3) + 8 * (reg >> 2)
+        if (rbk * 32 < nkh) {                                       // block holds rel_pos_h rows (wave-uniform)
+            const int kh0 = qh + Hp - 1 - r0;
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int r = rbk * 32 + acc_row(reg, lane);
-            const bf16 v = (bf16)(acc[reg] * inv_scale);
-            if (r < 2 * Hp - 1) {
-                const int kh = qh + Hp - 1 - r;
-                if (kh >= 0 && kh < Hp) *reinterpret_cast<bf16*>(thT + kh * 64 + ql * 2) = v;
-            } else {
-                const int rr = r - (2 * Hp - 1);
-                const int kw = qw + WP - 1 - rr;
-                if (rr < 2 * WP - 1 && kw >= 0 && kw < WP) *reinterpret_cast<bf16*>(twimg + ql * 64 + kw_phys(kw) * 2) = v;
+            for (int reg = 0; reg < 16; ++reg) {
+                const int off = (reg & 3) + 8 * (reg >> 2);
+                const int kh = kh0 - off;
+                const bool ok = (unsigned)kh < (unsigned)Hp;          // implies r < 2 Hp - 1 (r = qh + Hp - 1 - kh, qh < Hp); rows of the w part give kh < 0
+                *reinterpret_cast<bf16*>(ok ? th0 + kh * 64 : trash) = (bf16)(acc[reg] * inv_scale);
+            }
+        }
+        if (rbk * 32 + 32 > nkh) {                                  // block holds rel_pos_w rows
+            const int kw0 = qw + WP - 1 - (r0 - nkh);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int off = (reg & 3) + 8 * (reg >> 2);
+                const int kw = kw0 - off;                           // = qw + WP - 1 - rr
+                const bool ok = (unsigned)kw < (unsigned)WP;          // implies 0 <= rr < 2 WP - 1; h-part rows give kw >= WP, padding rows kw < 0
+                *reinterpret_cast<bf16*>(ok ? tw0 + kw_phys(kw) * 2 : trash) = (bf16)(acc[reg] * inv_scale);
             }
         }
     }

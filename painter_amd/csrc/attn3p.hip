@@ -74,7 +74,7 @@ __global__ __launch_bounds__(NTP, 2) void fwd_kernel(const bf16* __restrict__ qk
     if (valid) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) qf[s] = gfrag(base + (size_t)q * ldq, s, g);
-        build_tables3(twimg, thT, rcat, NRP, qf, q / WP, q % WP, Hp, 1.f / scale, lane);
+        build_tables3(twimg, thT, rcat, NRP, qf, q / WP, q % WP, Hp, 1.f / scale, lane, eimg + tid * 2);      // trash: the image region, built later
         T0 = *reinterpret_cast<const uint4*>(twimg + ql * 64 + 16 * g);          // same-wave LDS ops are ordered
         T1 = *reinterpret_cast<const uint4*>(twimg + ql * 64 + 32 + 16 * g);
         if (tables != nullptr) {

@@ -45,6 +45,16 @@ def main():
                 t = timeit(lambda: ops.attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables))
                 print("abl %3d  dq+dkv %.3f ms   [%s]" % (m, t, ", ".join(v for k, v in names.items() if m & k) or "full kernel"), flush=True)
         os.environ.pop("PA_ATTN3_DQ_ABL")
+        for m in (0, 16, 0):
+            os.environ["PA_ATTN3_DKV_ABL"] = str(m)
+            t = timeit(lambda: ops.attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables))
+            print("dkv abl %3d  dq+dkv %.3f ms   [%s]" % (m, t, "no query loop in dKV" if m else "full kernel"), flush=True)
+        os.environ.pop("PA_ATTN3_DKV_ABL")
+        for m in (0, 16, 32, 48, 0):
+            os.environ["PA_ATTN3_FWD_ABL"] = str(m)
+            t = timeit(lambda: ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True))
+            print("fwd abl %3d  forward %.3f ms   [%s]" % (m, t, ", ".join(v for k, v in {16: "no key loop", 32: "no table build"}.items() if m & k) or "full kernel"), flush=True)
+        os.environ.pop("PA_ATTN3_FWD_ABL")
         return
     lib.pa_attn_set_generation(4 if paired else 5)
     out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
