@@ -210,7 +210,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
                                                           bf16* __restrict__ dG, int L, int H, int Hp, int NRP, float scale, int nblk,
                                                           int xcd_map, int abl) {
     // abl (diagnostics, PA_ATTN3_DQ_ABL; results are WRONG with any bit set): 1 no r-space loop after the key loop, 2 no dG stores,
-    // 4 no dQ store, 16 no key loop
+    // 4 no dQ store, 16 no key loop, 32 no gather in the r-space loop, 64 no MFMA in the r-space loop
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, ql = lane & 31;
     const int trwg = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x / 2 ? 1 : -1);
@@ -419,25 +419,35 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         // The gather is branch-free (clamped addresses, selects) and one step ahead of its use, like the fragment loads: with a branch per
         // element the eleven steps cost ~2000 cycles each (coarse stamps: 22k of a workgroup's 150k cycles sat in this loop).
         const int nkh = 2 * Hp - 1;
+        // Three cases per step and half-wave: eight rel_pos_h entries, eight rel_pos_w entries, or the one step that straddles the two.
+        // The pure cases read unconditionally at base + constant offsets (an out-of-range entry is some other halfword of this
+        // workgroup's LDS and is selected away by ONE unsigned range test): ~5 VALU per element instead of ~12.
         auto gather = [&](int s, float (&gv)[8]) {
             const int r0 = 16 * s + 8 * g;
-            if (r0 + 7 < nkh) {                              // kh entries only (wave-uniform up to the half-wave split: both tests below are per half)
+            if (r0 + 7 < nkh) {
+                const int kh0 = qh + Hp - 1 - r0;                                  // entry t: kh0 - t
+                const unsigned char* base = thT + ql * 2 + (kh0 - 7) * 64;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
-                    const int khh = qh + Hp - 1 - (r0 + t);
-                    const bool ok = khh >= 0 && khh < Hp;
-                    const float v = (float)*reinterpret_cast<const bf16*>(thT + (ok ? khh : 0) * 64 + ql * 2);
-                    gv[t] = ok ? v : 0.f;
+                    const float v = (float)*reinterpret_cast<const bf16*>(base + (7 - t) * 64);
+                    gv[t] = (unsigned)(kh0 - t) < (unsigned)Hp ? v : 0.f;
+                }
+            } else if (r0 >= nkh) {
+                const int kw0 = qw + WP - 1 - (r0 - nkh);                          // entry t: kw0 - t (negative for the padding rows)
+                const float* base = twg + ql * WP + (kw0 - 7);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const float v = base[7 - t];
+                    gv[t] = (unsigned)(kw0 - t) < (unsigned)WP ? v : 0.f;
                 }
             } else {
 #pragma unroll
                 for (int t = 0; t < 8; ++t) {
                     const int r = r0 + t;
                     const int khh = qh + Hp - 1 - r;
-                    const int rr = r - nkh;
-                    const int kww = qw + WP - 1 - rr;
-                    const bool okh = r < nkh && khh >= 0 && khh < Hp;
-                    const bool okw = rr >= 0 && rr < 2 * WP - 1 && kww >= 0 && kww < WP;
+                    const int kww = qw + WP - 1 - (r - nkh);
+                    const bool okh = r < nkh && (unsigned)khh < (unsigned)Hp;
+                    const bool okw = r >= nkh && (unsigned)kww < (unsigned)WP;
                     const float vh = (float)*reinterpret_cast<const bf16*>(thT + (okh ? khh : 0) * 64 + ql * 2);
                     const float vw = twg[ql * WP + (okw ? kww : 0)];
                     gv[t] = okh ? vh : (okw ? vw : 0.f);
@@ -454,12 +464,17 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             const int sn = min(s + 1, nstep - 1);
             const bf16x8 rn[2] = {rfrag(r0, sn), rfrag(r1, sn)};
             float gnext[8];
-            gather(sn, gnext);
+            if (abl & 32) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) gnext[t] = gcur[t] + 1.f;
+            } else {
+                gather(sn, gnext);
+            }
             const bf16x8 gf = packfrag(gcur);
             if (!(abl & 2)) *reinterpret_cast<uint4*>(dgrow + 16 * s + 8 * g) = __builtin_bit_cast(uint4, gf);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
-                dq[db] = mfma(rf[db], gf, dq[db]);
+                if (!(abl & 64)) dq[db] = mfma(rf[db], gf, dq[db]);
                 rf[db] = rn[db];
             }
 #pragma unroll

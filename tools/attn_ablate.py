@@ -38,9 +38,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "epilogue":          # the default 4-wave dQ kernel: what is outside the key loop worth?
         lib.pa_attn_set_generation(0)
         out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
-        names = {1: "no r-space loop", 2: "no dG stores", 4: "no dQ store", 16: "no key loop"}
+        names = {1: "no r-space loop", 2: "no dG stores", 4: "no dQ store", 16: "no key loop", 32: "no r-space gather", 64: "no r-space MFMA"}
         for _ in range(2):
-            for m in (0, 1, 2, 4, 7, 16, 16 + 1, 16 + 7, 0):
+            for m in (0, 1, 2, 32, 64, 2 + 32 + 64, 16, 16 + 1, 0):
                 os.environ["PA_ATTN3_DQ_ABL"] = str(m)
                 t = timeit(lambda: ops.attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables))
                 print("abl %3d  dq+dkv %.3f ms   [%s]" % (m, t, ", ".join(v for k, v in names.items() if m & k) or "full kernel"), flush=True)
