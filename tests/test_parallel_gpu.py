@@ -1,0 +1,105 @@
+"""Two ranks, ONE MI355X: the data-parallel path with the HIP model as the gradient producer.
+
+RCCL refuses two ranks on one device, so the process group here is gloo over the GPU tensors -- everything else is the production path:
+`painter_amd.parallel.init_distributed`, `broadcast_parameters` on replicas that were seeded differently (main_train.py:190 seeds
+seed + rank), `model.grad_sync = GradSync()` with the buckets handed over from INSIDE the hand-written backward (side stream, reverse
+block order, in-place all-reduce of the weight matrices, flattened small tensors), two accumulation micro-steps as
+engine_train.py:85-90 runs them.  Every rank must end with the same gradients, and they must be the mean over ranks of what each
+rank's samples give without any exchange (computed by rank 0 alone afterwards)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+ACCUM = 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(cfg, seed):
+    from functools import partial
+
+    import torch.nn as nn
+
+    from oracle import painter_oracle as O
+    from painter_amd import models_painter
+    m = models_painter.Painter(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth,
+                               num_heads=cfg.num_heads, drop_path_rate=0.0, window_size=14, qkv_bias=True, mlp_ratio=4,
+                               norm_layer=partial(nn.LayerNorm, eps=1e-6), window_block_indexes=([0, 1], [3, 4]), residual_block_indexes=[],
+                               use_rel_pos=True, out_feature="last_feat", decoder_embed_dim=cfg.decoder_embed_dim, loss_func="smoothl1",
+                               compute_dtype="fp32")
+    m.load_state_dict(O.random_params(cfg, seed), strict=True)
+    return m.cuda()
+
+
+def _micro_steps(m, cfg, rank):
+    """ACCUM forward/backward passes on this rank's samples; gradients accumulate in p.grad (loss / ACCUM, engine_train.py:83)."""
+    from oracle import painter_oracle as O
+    for p in m.parameters():
+        p.grad = None
+    for k in range(ACCUM):
+        imgs, tgts, mask, valid = O.synthetic_batch(cfg, 1, 300 + 10 * rank + k, "random")
+        loss, _, _ = m(imgs.cuda(), tgts.cuda(), bool_masked_pos=mask.reshape(1, *cfg.grid).cuda(), valid=valid.cuda())
+        (loss / ACCUM).backward()
+    torch.cuda.synchronize()
+    return {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    from oracle import painter_oracle as O
+    from painter_amd import parallel
+    torch.cuda.set_device(0)
+    r, _, w = parallel.init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    cfg = O.small_config()
+    m = _build(cfg, 40 + rank)                                  # replicas start different, as the reference's seeding makes them
+    parallel.broadcast_parameters(m)
+    ref_sd = O.random_params(cfg, 40)
+    same_as_rank0 = all(torch.equal(p.detach().cpu(), ref_sd[n]) for n, p in m.named_parameters())
+    m.grad_sync = parallel.GradSync()
+    synced = _micro_steps(m, cfg, rank)
+    # every rank publishes a digest of what it ended with; rank 0 also recomputes both ranks' local gradients without any exchange
+    digest = {n: (float(g.double().sum()), float(g.double().abs().sum())) for n, g in synced.items()}
+    worst = None
+    if rank == 0:
+        m.grad_sync = None
+        local = [_micro_steps(m, cfg, rk) for rk in range(world)]
+        worst = 0.0
+        for n, g in synced.items():
+            mean = sum(loc[n] for loc in local) / world
+            worst = max(worst, float((g - mean).abs().max() / mean.abs().max().clamp_min(1e-12)))
+    q.put((rank, same_as_rank0, digest, worst))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_average_the_hip_models_gradients():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, same, digest, worst = q.get(timeout=600)
+        res[rank] = (same, digest, worst)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][0] and res[1][0], "broadcast_parameters left the replicas different"
+    assert res[0][1] == res[1][1], "ranks ended with different gradients"
+    assert res[0][2] is not None and res[0][2] < 2e-6, res[0][2]          # = mean over ranks of the local gradients (fp32 sum of two terms)
