@@ -43,20 +43,21 @@ def _build(cfg, seed):
     return m.cuda()
 
 
-def _micro_steps(m, cfg, rank):
+def _micro_steps(m, cfg, rank, params=None):
     """ACCUM forward/backward passes on this rank's samples; gradients accumulate in p.grad (loss / ACCUM, engine_train.py:83)."""
     from oracle import painter_oracle as O
-    for p in m.parameters():
+    params = params if params is not None else m
+    for p in params.parameters():
         p.grad = None
     for k in range(ACCUM):
         imgs, tgts, mask, valid = O.synthetic_batch(cfg, 1, 300 + 10 * rank + k, "random")
         loss, _, _ = m(imgs.cuda(), tgts.cuda(), bool_masked_pos=mask.reshape(1, *cfg.grid).cuda(), valid=valid.cuda())
         (loss / ACCUM).backward()
     torch.cuda.synchronize()
-    return {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+    return {n: p.grad.detach().clone() for n, p in params.named_parameters()}
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, wrapper=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     from oracle import painter_oracle as O
     from painter_amd import parallel
@@ -65,11 +66,14 @@ def _worker(rank, world, port, q):
     assert (r, w) == (rank, world)
     cfg = O.small_config()
     m = _build(cfg, 40 + rank)                                  # replicas start different, as the reference's seeding makes them
-    parallel.broadcast_parameters(m)
+    if wrapper:                                                 # main_train.py:340: the wrapper broadcasts rank 0's parameters and owns the exchange
+        ddp = torch.nn.parallel.DistributedDataParallel(m, device_ids=[0], find_unused_parameters=False)
+    else:
+        parallel.broadcast_parameters(m)
+        m.grad_sync = parallel.GradSync()
     ref_sd = O.random_params(cfg, 40)
     same_as_rank0 = all(torch.equal(p.detach().cpu(), ref_sd[n]) for n, p in m.named_parameters())
-    m.grad_sync = parallel.GradSync()
-    synced = _micro_steps(m, cfg, rank)
+    synced = _micro_steps(ddp if wrapper else m, cfg, rank, params=m)
     # every rank publishes a digest of what it ended with; rank 0 also recomputes both ranks' local gradients without any exchange
     digest = {n: (float(g.double().sum()), float(g.double().abs().sum())) for n, g in synced.items()}
     worst = None
@@ -85,12 +89,13 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_on_one_gpu_average_the_hip_models_gradients():
+@pytest.mark.parametrize("wrapper", [False, True], ids=["GradSync", "DistributedDataParallel"])
+def test_two_ranks_on_one_gpu_average_the_hip_models_gradients(wrapper):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(rk, world, port, q)) for rk in range(world)]
+    procs = [ctx.Process(target=_worker, args=(rk, world, port, q, wrapper)) for rk in range(world)]
     for p in procs:
         p.start()
     res = {}
