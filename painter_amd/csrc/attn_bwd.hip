@@ -501,7 +501,8 @@ static int relpos_grad_t(const T* dG, const T* qkv, int64_t ldq, float* drcat, f
     OpT<T> B{qkv, (size_t)ldq, ATT_HD, (size_t)ATT_HD};
     const int nku = (R + TT<T>::BK - 1) / TT<T>::BK;
     static const int want = [] { const char* v = getenv("PA_RELPOS_SPLITS"); return v ? atoi(v) : 16; }();      // 16: 45.7 us, 32: 52.6, 8: 67.9 (B=8)
-    int splits = want;
+    static const bool from_env = getenv("PA_RELPOS_SPLITS") != nullptr;
+    int splits = (!from_env && g_relpos_splits > 0) ? g_relpos_splits : want;
     if (splits > 32) splits = 32;          // workspace bound (pa_attn_bwd_relpos_workspace_bytes)
     if (splits < 1) splits = 1;
     if (splits > nku) splits = nku;

@@ -113,6 +113,11 @@ DEVI float wave_max(float v) {
     return v;
 }
 
+// tuning knob shared across translation units: K splits of the rel-pos table-gradient GEMM (0 = built-in default; pa_debug_set(6, n)).
+// The engine asks for 4 when that GEMM runs on the side stream beside the data-gradient chain (fewer, longer workgroups: 54.54 -> 54.35
+// ms/step), the stand-alone optimum is 16.
+inline int g_relpos_splits = 0;
+
 // exact (erf) GELU and its derivative -- nn.GELU default (Painter/models_painter.py:253)
 DEVI float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 DEVI float gelu_grad_f(float x) {

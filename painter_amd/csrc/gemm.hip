@@ -461,5 +461,6 @@ extern "C" int pa_abi_version(void) { return 1; }
 extern "C" int pa_debug_set(int which, int value) {
     if (which < 0 || which >= 8) return (int)hipErrorInvalidValue;
     g256::g_dbg[which] = value;
+    if (which == 6) g_relpos_splits = value;
     return 0;
 }

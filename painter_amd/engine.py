@@ -92,6 +92,7 @@ class HotPath:
         # workgroups (build.py: -fno-slp-vectorize); DESIGN.md section 6.
         self.use_side_stream = os.environ.get("PAINTER_AMD_SIDE_STREAM", "1") != "0"
         from ._lib import lib
+        lib.pa_debug_set(6, 4 if self.use_side_stream else 0)       # K splits of the rel-pos table-gradient GEMM beside the main chain: 16 -> 54.54, 4 -> 54.35, 2 -> 55.0 ms/step
         lib.pa_debug_set(3, 128 if self.use_side_stream else 0)      # wgrad GEMM workgroup target (gemm.hip: wgrad_fast_splits); round-2 sweep: 64 -> 59.7, 96 -> 57.7, 128 -> 57.7, 192 -> 58.9, 256 -> 59.2 ms/step
 
     def side_stream(self, device):
