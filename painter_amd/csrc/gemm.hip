@@ -299,7 +299,8 @@ static int linear_fwd_t(int epi, const T* x, int64_t ldx, const T* w, const floa
                         int64_t ldo, const float* resid, const float* rowscale, int rps, int M, int N, int K,
                         hipStream_t st) {
     if constexpr (std::is_same<T, bf16>::value) {
-        // tile shape: g_dbg-free policy knob PA_GEMM128 (0 never, 1 always, default 2 = when the 256 x 256 tiling needs more than one round)
+        // tile shape: PA_GEMM128 = 0 (default) never gemm128, 1 always, 2 when the 256 x 256 tiling needs more than one round; not a default
+        // anywhere (it only wins on fc1, by 5 %)
         static const int use128 = [] { const char* v = getenv("PA_GEMM128"); return v ? atoi(v) : 0; }();
         const int gmode = g256::g_dbg[4] > 0 ? g256::g_dbg[4] - 1 : use128;             // pa_debug_set(4, 1 + mode): A/B inside one process
         const bool multi_round = (int64_t)((M + 255) / 256) * ((N + 255) / 256) > 256;
