@@ -1,5 +1,10 @@
-"""Ablation of the software-pipelined dQ kernel (attn3s.hip, PA_ATTN3_ABL bit mask; results are wrong with any bit set, only the time
-matters): which ingredient of a tile iteration costs what.  Times the dQ + dKV pair; dKV is constant, so differences are dQ's."""
+"""Ablation as a profiler for the generation-3 attention kernels: runtime bit masks switch pieces of a kernel off (results are then
+WRONG, only the time matters) and the difference is what the piece costs in place.
+    python tools/attn_ablate.py              software-pipelined dQ (attn3s.hip, PA_ATTN3_ABL): staging, barrier, LDS fragment loads, exp, MFMA groups
+    python tools/attn_ablate.py paired       paired 8-wave dQ (attn3p.hip, PA_ATTN3_ABL)
+    python tools/attn_ablate.py epilogue     the default 4-wave kernels: dQ key loop / r-space step / stores (PA_ATTN3_DQ_ABL), dKV query loop
+                                             (PA_ATTN3_DKV_ABL), forward key loop and table build (PA_ATTN3_FWD_ABL)
+Times the dQ + dKV pair (dKV is constant, so differences are dQ's) or the forward."""
 import os
 import sys
 
