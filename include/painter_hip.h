@@ -36,6 +36,9 @@ enum {
     PA_EPI_BIAS_RESID = 3  /* out(f32) = resid + rowscale[row / rows_per_sample] * (x.W^T + b) */
 };
 
+/* Bumped whenever an entry point's argument list changes (2: `tables` in pa_attn_fwd / pa_attn_bwd; 3: `head_dim` in the attention and
+ * rel-pos entry points).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
+#define PA_ABI_VERSION 3
 int pa_abi_version(void);
 /* diagnostics only (tools/): which = 0 start-up stagger of alternate workgroup rows of the 256x256 GEMM in shader cycles,
  * 1 drop that kernel's epilogue stores (never set by the product path); 3 = TUNING, set by the engine: target number of workgroups
@@ -83,14 +86,12 @@ int pa_relpos_pack(int dtype, const float* rel_pos_h, const float* rel_pos_w, vo
  * tables: NULL (inference), or pa_attn_tables_bytes() of device memory that receives the per-query bias tables the
  * backward reuses (only the 28-token-wide bf16 kernels write it; the size is 0 for every other case). */
 int64_t pa_attn_tables_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp);
-/* 0 = default kernels for the grid (generation 3, 4-wave build, where it applies), 3 = the same explicitly, 4 = generation 3 in
- * its paired 8-wave build, 2 = never use the 28-token-wide generation-3 kernels (diagnostics, A/B, cross-generation tests) */
+/* 0 = default kernels for the grid (generation 3 where it applies), 3 = the same explicitly, 2 = never use the 28-token-wide
+ * generation-3 kernels (diagnostics, A/B, cross-generation tests) */
 int pa_attn_set_generation(int generation);
 /* diagnostics: enable != 0 runs the generation-3 dQ kernel with s_memtime stamps (two workgroups, waves 0 / 1, 64 tiles, 8 slots);
  * host_out (may be NULL) receives the 2 x 2 x 64 x 8 stamps of the last traced launch */
 int pa_attn_trace(int enable, unsigned long long* host_out);
-/* diagnostics: s_memtime stamps of the paired dQ kernel, 2 x 64 values (PA_ATTN3_ABL bit 512; csrc/attn3p.hip) */
-int pa_attn_trace_paired(unsigned long long* host_out);
 int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse,
                 void* tables, int batch, int L, int heads, int Hp, int Wp, float scale, hipStream_t stream);
 

@@ -55,6 +55,11 @@ class _Lib:
                 fn = getattr(dll, name)          # AttributeError here = header/library drift: fail loudly
                 fn.restype = ret
                 fn.argtypes = args
+            want = int(re.search(r"#define\s+PA_ABI_VERSION\s+(\d+)", open(HEADER).read()).group(1))
+            got = dll.pa_abi_version()
+            if got != want:          # e.g. a stale A/B build behind PAINTER_AMD_LIB: its argument lists would be shifted
+                raise RuntimeError("painter_amd: %s has C ABI version %d, include/painter_hip.h declares %d -- rebuild it "
+                                   "(python -m painter_amd.build --force)" % (LIB_PATH, got, want))
             self._dll = dll
         return self._dll
 

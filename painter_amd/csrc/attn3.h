@@ -9,11 +9,3 @@ int attn3_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t
               int Hp, int Wp, float scale, hipStream_t st);
 int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const float* delta,
               void* tables, bf16* dqkv, bf16* dG, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st);
-// paired build (attn3p.hip): 8-wave workgroups, matrix / VALU phases in anti-phase
-int attn3p_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t ldo, float* lse, void* tables, int Bn, int L, int H,
-               int Hp, int Wp, float scale, hipStream_t st);
-int attn3p_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const float* delta,
-               void* tables, bf16* dqkv, bf16* dG, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st);
-// software-pipelined dQ kernel (attn3s.hip): operand fragments requested one iteration ahead, 16 MFMAs back to back
-int attn3s_dq(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, void* tables, bf16* dqkv,
-              bf16* dG, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st);

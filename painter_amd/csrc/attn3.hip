@@ -678,25 +678,15 @@ __global__ void prep_kernel(const float* __restrict__ lse, const float* __restri
 
 }   // namespace a3
 
-// PA_ATTN3=0 / pa_attn_set_generation(2): keep the generation-2 kernels for every grid (A/B runs, cross-generation tests);
-// PA_ATTN3_PAIRED=1 / pa_attn_set_generation(4): generation 3 in its paired 8-wave build (attn3p.hip) instead of the 4-wave build --
-// measured slower on MI355X (forward 213 vs 146 us, backward 509 vs 420 us at B' = 8), kept as the experiment it is
+// PA_ATTN3=0 / pa_attn_set_generation(2): keep the generation-2 kernels for every grid (A/B runs, cross-generation tests).  The paired
+// 8-wave build and the software-pipelined dQ of round 2 both measured slower and live in tools/experiments/ (DESIGN.md section 4.5).
 static int g_attn_generation = 0;
-static bool attn3_paired() {
-    static const int on = [] { const char* e = getenv("PA_ATTN3_PAIRED"); return e ? atoi(e) : 0; }();
-    return g_attn_generation == 4 || (on && g_attn_generation != 3);
-}
 extern "C" int pa_attn_set_generation(int generation) {
-    if (generation != 0 && (generation < 2 || generation > 5)) return (int)hipErrorInvalidValue;
+    if (generation != 0 && generation != 2 && generation != 3) return (int)hipErrorInvalidValue;
     g_attn_generation = generation;
     return 0;
 }
 static int g_attn_trace = 0;
-// PA_ATTN3_PIPE=1 / pa_attn_set_generation(5): software-pipelined backward (attn3s.hip)
-static bool attn3_pipelined() {
-    static const int on = [] { const char* e = getenv("PA_ATTN3_PIPE"); return e ? atoi(e) : 0; }();
-    return g_attn_generation == 5 || (on && g_attn_generation == 0);
-}
 extern "C" int pa_attn_trace(int enable, unsigned long long* host_out) {
     g_attn_trace = enable;
     if (host_out != nullptr) return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(a3::g_trace), sizeof(a3::g_trace));
@@ -718,7 +708,6 @@ static int a3_xcd_map_on() {
 int attn3_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t ldo, float* lse, void* tables, int Bn, int L, int H,
               int Hp, int Wp, float scale, hipStream_t st) {
     using namespace a3;
-    if (attn3_paired()) return attn3p_fwd(qkv, ldq, rcat, out, ldo, lse, tables, Bn, L, H, Hp, Wp, scale, st);
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
     // PA_ATTN3_FWD_STAGES: 1 (default) = single K/V stage, 4 workgroups per CU; 2 = double-buffered, one barrier per tile
     static const int stages = [] { const char* v = getenv("PA_ATTN3_FWD_STAGES"); return v ? atoi(v) : 1; }();
@@ -735,7 +724,6 @@ int attn3_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t
 int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const float* delta,
               void* tables, bf16* dqkv, bf16* dG, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st) {
     using namespace a3;
-    if (attn3_paired()) return attn3p_bwd(qkv, ldq, rcatT, dout, lddo, lse, delta, tables, dqkv, dG, Bn, L, H, Hp, Wp, scale, st);
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
     const int nblk = (L / 32 + NW - 1) / NW;
     unsigned char* tb = reinterpret_cast<unsigned char*>(tables);
@@ -748,9 +736,7 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
     // PA_ATTN3_DQ_WAVES / PA_ATTN3_DKV_WAVES: waves per SIMD the register allocation aims at (2 or 3)
     static const int dq_w = [] { const char* v = getenv("PA_ATTN3_DQ_WAVES"); return v ? atoi(v) : 2; }();
     static const int dkv_w = [] { const char* v = getenv("PA_ATTN3_DKV_WAVES"); return v ? atoi(v) : 2; }();
-    if (attn3_pipelined() && !g_attn_trace) {
-        if ((e = attn3s_dq(qkv, ldq, rcatT, dout, lddo, lse, tables, dqkv, dG, Bn, L, H, Hp, Wp, scale, st))) return e;
-    } else {
+    {
         static const size_t pad = [] { const char* v = getenv("PA_ATTN3_LDS_PAD"); return v ? (size_t)atoi(v) : (size_t)0; }();   // diagnostics: fewer workgroups per CU
         const size_t smem = 2 * (size_t)STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG + (size_t)ATT_HD * (NRP * 2 + 16) + pad;
         auto kern = g_attn_trace ? bwd_dq_kernel<2, true, true> : (dq_w == 3 ? bwd_dq_kernel<3, false> : bwd_dq_kernel<2, A3_NDL>);

@@ -1,5 +1,5 @@
-// Pieces shared by the two builds of the generation-3 attention kernels (attn3.hip: 4-wave workgroups; attn3p.hip: 8-wave workgroups
-// whose two half-groups run matrix and VALU phases in anti-phase).  See attn3.hip for the scheme (rel-pos bias as a one-hot contraction).
+// Pieces of the generation-3 attention kernels (attn3.hip, 4-wave workgroups; the retired paired 8-wave and software-pipelined builds
+// under tools/experiments/ used them too).  See attn3.hip for the scheme (rel-pos bias as a one-hot contraction).
 #pragma once
 #include "attn_tile.h"
 #include <type_traits>

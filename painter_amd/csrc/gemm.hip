@@ -4,7 +4,6 @@
 #include <cstdlib>
 #include "gemm_engine.h"
 #include "gemm256.h"
-#include "gemm128.h"
 #include "../../include/painter_hip.h"
 
 // ------------------------------------------------------------------------------- epilogues
@@ -299,23 +298,6 @@ static int linear_fwd_t(int epi, const T* x, int64_t ldx, const T* w, const floa
                         int64_t ldo, const float* resid, const float* rowscale, int rps, int M, int N, int K,
                         hipStream_t st) {
     if constexpr (std::is_same<T, bf16>::value) {
-        // tile shape: PA_GEMM128 = 0 (default) never gemm128, 1 always, 2 when the 256 x 256 tiling needs more than one round; not a default
-        // anywhere (it only wins on fc1, by 5 %)
-        static const int use128 = [] { const char* v = getenv("PA_GEMM128"); return v ? atoi(v) : 0; }();
-        const int gmode = g256::g_dbg[4] > 0 ? g256::g_dbg[4] - 1 : use128;             // pa_debug_set(4, 1 + mode): A/B inside one process
-        const bool multi_round = (int64_t)((M + 255) / 256) * ((N + 255) / 256) > 256;
-        if ((gmode == 1 || (gmode == 2 && multi_round)) && g128::ok(M, N, K, ldx, K)) {
-            switch (epi) {
-            case PA_EPI_BIAS:
-                return g128::launch(x, ldx, w, K, Epi4Bias<bf16>{(bf16*)out, (size_t)ldo, bias, M, N}, M, N, K, st);
-            case PA_EPI_BIAS_F32:
-                return g128::launch(x, ldx, w, K, Epi4Bias<float>{(float*)out, (size_t)ldo, bias, M, N}, M, N, K, st);
-            case PA_EPI_BIAS_GELU:
-                return g128::launch(x, ldx, w, K, Epi4BiasGelu{(bf16*)out2, (bf16*)out, (size_t)ldo, bias, M, N}, M, N, K, st);
-            case PA_EPI_BIAS_RESID:
-                return g128::launch(x, ldx, w, K, Epi4BiasResid{(float*)out, resid, (size_t)ldo, bias, rowscale, rps, M, N}, M, N, K, st);
-            }
-        }
         if (g256::ok(M, N, K, false, false, ldx, K)) {
             switch (epi) {
             case PA_EPI_BIAS:
@@ -458,7 +440,7 @@ extern "C" int pa_linear_wgrad(int dtype, const void* dy, int64_t lddy, const vo
     return linear_wgrad_t<float>((const float*)dy, lddy, (const float*)x, ldx, dw, (float*)workspace, M, N, K, st);
 }
 
-extern "C" int pa_abi_version(void) { return 1; }
+extern "C" int pa_abi_version(void) { return PA_ABI_VERSION; }
 extern "C" int pa_debug_set(int which, int value) {
     if (which < 0 || which >= 8) return (int)hipErrorInvalidValue;
     g256::g_dbg[which] = value;

@@ -28,6 +28,22 @@ _SIDE_EXTRA = os.environ.get("PAINTER_AMD_SIDE_EXTRA", "1") != "0"     # rel-pos
 _DBG_TRACE = os.environ.get("PAINTER_AMD_DEBUG_TRACE", "0") == "1"     # checksums of the backward's intermediates -> HotPath.trace
 
 
+_SIDE_STREAM = os.environ.get("PAINTER_AMD_SIDE_STREAM", "1") != "0"
+_configured = False
+
+
+def _configure_library():
+    """Process-wide tuning knobs of libpainter_hip.so, set ONCE from the environment (they are globals of the library: setting them per
+    module instance would let the last constructed model decide for every model of the process)."""
+    global _configured
+    if _configured:
+        return
+    from ._lib import lib
+    lib.pa_debug_set(6, 4 if _SIDE_STREAM else 0)       # K splits of the rel-pos table-gradient GEMM beside the main chain: 16 -> 54.54, 4 -> 54.35, 2 -> 55.0 ms/step
+    lib.pa_debug_set(3, 128 if _SIDE_STREAM else 0)     # wgrad GEMM workgroup target (gemm.hip: wgrad_fast_splits); round-2 sweep: 64 -> 59.7, 96 -> 57.7, 128 -> 57.7, 192 -> 58.9, 256 -> 59.2 ms/step
+    _configured = True
+
+
 class HotPathConfig:
     def __init__(self, img_size, patch_size, embed_dim, depth, num_heads, mlp_ratio, decoder_embed_dim,
                  pretrain_img_size, pretrain_use_cls_token, use_rel_pos, ln_eps, loss_func, seggpt, drop_path_rate):
@@ -90,10 +106,8 @@ class HotPath:
         # stream (+3.5 % at B=8; PAINTER_AMD_SIDE_STREAM=0 turns it off).  This mode exposed two things, both fixed: a cross-stream
         # allocator hazard on the gradient buckets, and SLP-packed fp32 VALU code mis-computing beside another kernel's MFMA
         # workgroups (build.py: -fno-slp-vectorize); DESIGN.md section 6.
-        self.use_side_stream = os.environ.get("PAINTER_AMD_SIDE_STREAM", "1") != "0"
-        from ._lib import lib
-        lib.pa_debug_set(6, 4 if self.use_side_stream else 0)       # K splits of the rel-pos table-gradient GEMM beside the main chain: 16 -> 54.54, 4 -> 54.35, 2 -> 55.0 ms/step
-        lib.pa_debug_set(3, 128 if self.use_side_stream else 0)      # wgrad GEMM workgroup target (gemm.hip: wgrad_fast_splits); round-2 sweep: 64 -> 59.7, 96 -> 57.7, 128 -> 57.7, 192 -> 58.9, 256 -> 59.2 ms/step
+        self.use_side_stream = _SIDE_STREAM
+        _configure_library()
 
     def side_stream(self, device):
         s = self._side.get(device)

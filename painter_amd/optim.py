@@ -227,7 +227,8 @@ class NativeScalerWithGradNormCount:
         if scale is None:
             scale = torch.ones((), dtype=torch.float32, device=info.device)
         # scalar plumbing for GradScaler.update(); an overflowed sum of squares counts as inf (pa_adamw_step skips on it too)
-        found_inf = ((info[1:2] != 0) | ~torch.isfinite(info[0:1])).to(torch.float32)
+        # (ONE predicate on both sides: csrc/optim.hip skip_step() skips on `!(sumsq <= 3.0e38)`, which also covers NaN / inf)
+        found_inf = ((info[1:2] != 0) | ~(info[0:1] <= 3.0e38)).to(torch.float32)
         norm = torch.sqrt(info[0]) / scale.reshape(())
         optimizer.step(grad_scale=scale, found_inf=found_inf, max_norm=clip_grad)    # pass 2
         if self._scaler.is_enabled():

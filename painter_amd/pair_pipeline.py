@@ -14,6 +14,7 @@ passes, csrc/pair_io.hip), batched over the samples of a step and bit-identical 
 from this image, so those few lines are NOT pinned -- in a deployment with torchvision call its own get_params and fill the spec).
 There is no CPU fallback.
 """
+import collections
 import math
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
@@ -143,21 +144,25 @@ class DevicePairPipeline:
             raise RuntimeError("painter_amd.pair_pipeline runs its pixel kernels on an MI355X only (no CPU fallback); got %s" % device)
         self.H, self.W = input_size
         self.side = input_size[1]                      # RandomResizedCrop(args.input_size[1]) -> side x side (main_train.py:234)
-        self._tables = {}
+        self._tables = collections.OrderedDict()       # (kind, in, out) -> device table(s), least recently used first
         self._pin = None                               # pinned staging buffer for the packed crop boxes
         self._pin_event = None
 
     def _table(self, kind, in_size, out_size):
+        """Pillow's per-axis tap / coefficient table for one (in, out) size pair, cached on the device.  Random crops make most lookups of
+        a training step misses; a miss costs the host-side table build plus one or two small pageable uploads (a few KB each)."""
         key = (kind, in_size, out_size)
         t = self._tables.get(key)
-        if t is None:
+        if t is not None:
+            self._tables.move_to_end(key)
+        else:
             if kind == "bicubic":
                 bounds, coeffs, ksize = RS.bicubic_tables(in_size, out_size)
                 t = (torch.from_numpy(bounds).to(self.device), torch.from_numpy(coeffs).to(self.device), ksize)
             else:
                 t = torch.from_numpy(RS.pil_nearest_table(in_size, out_size)).to(self.device)
-            if len(self._tables) > 4096:               # crop sizes vary per sample: bound the cache
-                self._tables.clear()
+            while len(self._tables) >= 4096:           # crop sizes vary per sample: bound the cache, oldest entry first
+                self._tables.popitem(last=False)
             self._tables[key] = t
         return t
 
@@ -257,7 +262,8 @@ class DevicePairPipeline:
 
     def resized_crop_batch(self, pictures, boxes, nearest, out):
         """pictures: decoded uint8 [H][W][3] numpy arrays; boxes: (top, left, h, w) each; nearest: bool each; out: uint8
-        [n][side][side][3] CUDA tensor written in place.  Only the crop boxes travel to the device, packed in one pinned buffer."""
+        [n][side][side][3] CUDA tensor written in place.  The crop boxes travel to the device packed in one pinned buffer, the job table in
+        one more copy; resize tables for (in, out) size pairs not seen recently are built and uploaded by _table() (2-4 small copies each)."""
         n = len(pictures)
         oh, ow = out.shape[1], out.shape[2]
         assert out.is_cuda and out.dtype == torch.uint8 and out.is_contiguous() and out.shape[0] == n and out.shape[3] == 3
@@ -309,7 +315,8 @@ class DevicePairPipeline:
         mid = torch.empty(max(mid_rows, 1) * ow * 3, dtype=torch.uint8, device=self.device)
         check(lib.pa_resized_crop_u8_batch(jobs_d.data_ptr(), mid.data_ptr(), n, max(b[2] for b in boxes), max(b[3] for b in boxes), oh, ow,
                                            _stream()), "pa_resized_crop_u8_batch")
-        del keep                                        # the tables stay referenced by the cache until the launches are enqueued
+        del keep                                        # `keep` held the tables (the cache may evict them) until the launches were enqueued;
+                                                        # after that the stream-ordered allocator cannot hand their memory out early
         return out
 
     def resized_crop_tensor_modes(self, canvas, boxes, modes):

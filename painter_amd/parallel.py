@@ -91,7 +91,15 @@ def broadcast_parameters(module, src=0, process_group=None):
         return
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
-            dist.broadcast(t.data, src=src, group=process_group)
+            # through a staging tensor and Tensor.copy_: a write through `.data` (or by the collective itself) does not bump the
+            # parameter's version counter, and the engine's cached bf16 weight copies are keyed on it (engine.HotPath.w) -- a
+            # replica that had already run a forward would keep multiplying by its OLD weights.
+            buf = t.detach().clone()
+            dist.broadcast(buf, src=src, group=process_group)
+            t.copy_(buf)
+    hot = getattr(module, "_hot", None)
+    if hot is not None:
+        hot._wcache.clear()                        # belt and braces: the shadow copies are rebuilt on the next forward
 
 
 def _ipc_env():
