@@ -20,9 +20,11 @@ all-reduce (RCCL, bucketed, overlapped with backward) is inside the step.  Print
                  own): algorithmic FLOPs of its launches / their summed duration, against the same peak; `kernels` lists every family.
                  `traffic` = HBM bytes per launch of the dominant family's largest forward instantiation from the PMC passes
                  (profiles/roofline_traffic.json, tools/pmc_traffic.py) or null.
+  sustained    = a second timed region right after the first: the same step repeated until --min-seconds (default 5 s) have elapsed
+                 -- clocks and temperatures at steady state; `value` stays the contract's EXACTLY-K-steps number.
   cpu_baseline = the CPU oracle (oracle/painter_oracle.py = the reference's forward restated op for op in PyTorch-CPU, kind "port":
-                 /root/reference does not exist on the GPU box) on the host cores, all of them, B = 1, fp32: eval forward and train
-                 forward+backward, 1 warm-up + 3 timed runs each; value = fwd+bwd images/sec from the median.
+                 /root/reference does not exist on the GPU box) on the host cores, B = 1, fp32, thread count swept over {16, 32, 64, all
+                 physical cores}: value = train forward+backward images/sec at the best count, the all-cores figure beside it.
 """
 import argparse
 import json
@@ -39,6 +41,13 @@ sys.path.insert(0, ROOT)
 
 FLOP_BLOCKS_FWD_BWD = 4.034e12     # attention + MLP blocks, fwd+bwd, per image
 FLOP_MODEL_FWD_BWD = 4.769e12      # whole model
+# --model vit_huge (BASELINE configs[4], SURVEY.md 8d config 5: ViT-H/14, not a reference factory): blocks-only / whole model
+MODELS = {
+    "vit_large": dict(factory="painter_vit_large_patch16_input896x448", blocks=FLOP_BLOCKS_FWD_BWD, whole=FLOP_MODEL_FWD_BWD, head_dim=64,
+                      workload="painter_vit_large_patch16_input896x448 %s batch=%d/GPU fwd+bwd on %dxMI355X (BASELINE configs[1])"),
+    "vit_huge": dict(factory="painter_vit_huge_patch14_input896x448", blocks=10.76e12, whole=11.66e12, head_dim=80,
+                     workload="painter_vit_huge_patch14_input896x448 %s batch=%d/GPU fwd+bwd on %dxMI355X (BASELINE configs[4]; untuned generic attention kernels)"),
+}
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
 
@@ -88,31 +97,36 @@ class KernelTimer:
         "linear_pixshuf": ("gemm256_fwd", lambda a, k: _mnk(a[0].shape[0], a[0].shape[1], a[1].shape[0])),
         "linear_dgrad": ("gemm256_dgrad", lambda a, k: _mnk(a[0].shape[0], a[0].shape[1], a[1].shape[1])),      # (dy [M,N], w [N,K])
         "linear_wgrad": ("gemm256_wgrad", lambda a, k: _mnk(a[0].shape[0], a[0].shape[1], a[1].shape[1])),      # (dy [M,N], x [M,K])
-        "attn_fwd": ("attention_fwd", lambda a, k: 4.0 * a[2] * a[4] * a[3] * a[3] * 64),                       # (qkv, rcat, batch, L, heads)
-        "attn_bwd_core": ("attention_bwd", lambda a, k: 10.0 * a[6] * a[8] * a[7] * a[7] * 64),                 # 2.5 x forward
+        "attn_fwd": ("attention_fwd", lambda a, k: 4.0 * a[2] * a[4] * a[3] * a[3] * a[1].shape[1]),             # (qkv, rcat [NRP, hd], batch, L, heads)
+        "attn_bwd_core": ("attention_bwd", lambda a, k: 10.0 * a[6] * a[8] * a[7] * a[7] * a[1].shape[1]),       # 2.5 x forward
     }
     NAMES = {
         "gemm256_fwd": "g256::gemm256_kernel<false,false,*> (nn.Linear forward: qkv, proj, fc1+GELU, fc2, decoder_embed)",
         "gemm256_dgrad": "g256::gemm256_kernel<false,true,*> (nn.Linear data gradient dX = dY.W)",
         "gemm256_wgrad": "g256::gemm256_kernel<true,true,Epi4Slab> + slab_reduce (weight gradient dW = dY^T.X)",
-        "attention_fwd": "a3::fwd_kernel (fused attention forward, rel-pos bias on the matrix pipe)",
-        "attention_bwd": "a3::bwd_dq_kernel + a3::bwd_dkv_kernel + delta/prep (fused attention backward, 2.5x the forward's FLOPs)",
+        "attention_fwd": "a3::fwd_kernel (fused attention forward, rel-pos bias on the matrix pipe; head_dim 80: attn_fwd_kernel<bf16,4,80>)",
+        "attention_bwd": "a3::bwd_dq_kernel + a3::bwd_dkv_kernel + delta/prep (fused attention backward, 2.5x the forward's FLOPs; head_dim 80: attn_bwd_dq/dkv_kernel<bf16,*,80>)",
     }
 
     def __init__(self, ops_mod):
         self.ops, self.active = ops_mod, False
         self.rec = {}
+        self.depth = 0          # ops.linear_gelu calls the (wrapped) module-global ops.linear_fwd: only the outermost bracket counts
 
     def install(self):
         for fname, (family, flops) in self.OPS.items():
             orig = getattr(self.ops, fname)
 
             def wrapped(*a, _orig=orig, _family=family, _flops=flops, **kw):
-                if not self.active:
+                if not self.active or self.depth > 0:
                     return _orig(*a, **kw)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                r = _orig(*a, **kw)
+                self.depth += 1
+                try:
+                    r = _orig(*a, **kw)
+                finally:
+                    self.depth -= 1
                 e1.record()
                 ent = self.rec.setdefault(_family, {"events": [], "flops": 0.0})
                 ent["events"].append((e0, e1))
@@ -132,10 +146,12 @@ class KernelTimer:
         return out
 
 
-def cpu_baseline(budget_s=60.0):
-    """The CPU oracle at B=1 (ViT-L, 896x448, fp32) on the host's physical cores: train forward+backward (1 warm-up + up to 3 timed
-    runs) and eval forward (up to 3 timed runs after the warm-up above), time-boxed to about `budget_s` seconds of timed work so that
-    the default bench run stays within minutes (at least one timed run of each is always taken)."""
+def cpu_baseline(budget_s=100.0):
+    """The CPU oracle at B=1 (ViT-L, 896x448, fp32) on the host's cores.  More threads are not faster at B = 1 (round 2 measured 0.050
+    images/s on 128 threads where 32 threads gave 0.11), so the thread count is SWEPT: one warm-up forward+backward, then one timed
+    forward+backward at each of {16, 32, 64, all physical cores}; the best count gets up to two more timed runs and the eval forwards.
+    value = forward+backward images/sec at the best thread count (median of its runs); the all-cores figure is reported beside it.
+    Time-boxed to about `budget_s` seconds so that the default bench run stays within minutes."""
     import statistics
 
     from oracle import painter_oracle as O
@@ -145,8 +161,7 @@ def cpu_baseline(budget_s=60.0):
         phys = psutil.cpu_count(logical=False) or logical
     except Exception:
         phys = logical
-    nthreads = min(logical, phys)                  # one thread per physical core: SMT siblings only add contention at B = 1
-    torch.set_num_threads(nthreads)
+    phys = min(logical, phys)                      # one thread per physical core at most: SMT siblings only add contention at B = 1
     cfg = O.vit_large_config()
     P = {k: v.requires_grad_(True) for k, v in O.random_params(cfg, 1).items()}
     imgs, tgts, mask, valid = O.synthetic_batch(cfg, 1, 1234, "half")
@@ -161,24 +176,36 @@ def cpu_baseline(budget_s=60.0):
         loss, _, _ = O.forward(P, cfg, imgs, tgts, mask, valid.clone())
         loss.backward()
 
-    def timed(fn, budget):
-        ts = []
-        while len(ts) < 3 and (not ts or sum(ts) + ts[-1] <= budget):
-            t0 = time.time()
-            fn()
-            ts.append(time.time() - t0)
-        return statistics.median(ts), ts
+    def once(fn):
+        t0 = time.time()
+        fn()
+        return time.time() - t0
 
-    t0 = time.time()
-    fwd_bwd()                                      # warm-up (allocator, thread pool, oneDNN primitives)
-    warm = time.time() - t0
-    tt, tts = timed(fwd_bwd, 0.7 * budget_s)
-    te, tes = timed(fwd_eval, 0.3 * budget_s)
-    return {"value": round(1.0 / tt, 5), "unit": "images/sec", "cores": torch.get_num_threads(), "logical_cpus": logical,
-            "physical_cores": phys, "kind": "port", "eval_forward_images_per_sec": round(1.0 / te, 5),
-            "sample": "oracle/painter_oracle.py (the reference forward restated op for op, PyTorch-CPU fp32), ViT-L 896x448, B=1, %d threads; "
-                      "warm-up forward+backward %.1f s, then timed forward+backward %s s and eval forward %s s (time-boxed to ~%d s); value = 1 / "
-                      "median forward+backward" % (nthreads, warm, ["%.2f" % t for t in tts], ["%.2f" % t for t in tes], int(budget_s))}
+    t_start = time.time()
+    counts = sorted({n for n in (16, 32, 64, phys) if n <= phys} | {phys})
+    torch.set_num_threads(min(32, phys))
+    warm = once(fwd_bwd)                           # warm-up (allocator, thread pool, oneDNN primitives)
+    sweep = {}
+    for n in counts:
+        torch.set_num_threads(n)
+        sweep[n] = [once(fwd_bwd)]
+    best = min(sweep, key=lambda n: sweep[n][0])
+    torch.set_num_threads(best)
+    while len(sweep[best]) < 3 and time.time() - t_start + sweep[best][-1] < 0.8 * budget_s:
+        sweep[best].append(once(fwd_bwd))
+    tt = statistics.median(sweep[best])
+    tes = [once(fwd_eval)]
+    while len(tes) < 3 and time.time() - t_start + tes[-1] < budget_s:
+        tes.append(once(fwd_eval))
+    te = statistics.median(tes)
+    return {"value": round(1.0 / tt, 5), "unit": "images/sec", "cores": best, "logical_cpus": logical, "physical_cores": phys,
+            "kind": "port", "eval_forward_images_per_sec": round(1.0 / te, 5),
+            "all_cores_value": round(1.0 / sweep[phys][0], 5),
+            "thread_sweep_fwd_bwd_seconds": {str(n): [round(t, 2) for t in ts] for n, ts in sweep.items()},
+            "sample": "oracle/painter_oracle.py (the reference forward restated op for op, PyTorch-CPU fp32), ViT-L 896x448, B=1; warm-up "
+                      "forward+backward %.1f s, then one timed forward+backward per thread count %s, the best count (%d threads) re-timed "
+                      "%s s, eval forward there %s s; value = 1 / median forward+backward at %d threads; all %d physical cores: %.5f images/s"
+                      % (warm, counts, best, ["%.2f" % t for t in sweep[best]], ["%.2f" % t for t in tes], best, phys, 1.0 / sweep[phys][0])}
 
 
 def optimizer_step_ms(model, step_fn):
@@ -216,6 +243,15 @@ def optimizer_step_ms(model, step_fn):
     return res
 
 
+def _lib_sha16():
+    import hashlib
+    from painter_amd._lib import LIB_PATH
+    try:
+        return hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -241,7 +277,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (BASELINE configs[1]: 8)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (BASELINE configs[1]: 8; --model vit_huge: 4 = global 32 on 8 GPUs)")
+    ap.add_argument("--model", default="vit_large", choices=sorted(MODELS))
+    ap.add_argument("--min-seconds", type=float, default=5.0, help="length of the second, sustained timed region (0 = skip)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--profile-steps", type=int, default=2, help="steps of the separate, event-instrumented pass after the timed region (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -265,7 +303,10 @@ def main():
         import torch.distributed as dist
         assert dist.get_world_size() == world
 
-    model = models_painter.painter_vit_large_patch16_input896x448(compute_dtype=args.dtype)
+    spec = MODELS[args.model]
+    if args.batch is None:
+        args.batch = 8 if args.model == "vit_large" else 4
+    model = getattr(models_painter, spec["factory"])(compute_dtype=args.dtype)
     randomize_parameters(model, seed=1 + rank)              # replicas start different (main_train.py:190) ...
     model = model.to(dev)
     model.train(not args.eval)
@@ -307,6 +348,25 @@ def main():
         dt = float(t.item())
         n_ranks = torch.distributed.get_world_size()
 
+    # ---- sustained region: the same step until --min-seconds have gone by (every rank runs the same number of steps, fixed
+    # beforehand from the first region's pace, so the collectives stay matched); `value` above stays the exactly-K-steps number
+    sustained = None
+    if args.min_seconds > 0:
+        n_sus = max(args.steps, int(args.min_seconds / (dt / args.steps)) + 1)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        torch.cuda.synchronize()
+        barrier()
+        dts = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dts], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dts = float(t.item())
+        sustained = {"steps": n_sus, "seconds": round(dts, 3), "value": round(n_ranks * args.batch * n_sus / dts, 3),
+                     "ms_per_step": round(dts / n_sus * 1e3, 3)}
+
     # ---- separate profiled pass (never compare a profiled arm with an un-profiled one: `value` above is un-instrumented)
     kernels = {}
     if args.profile_steps > 0 and not distributed:          # single rank only: the extra steps would need every rank's all-reduce
@@ -323,6 +383,11 @@ def main():
         kernels = timer.results(peak)
         for v in kernels.values():
             v["ms_per_step"] = round(v["kernel_ms_total"] / args.profile_steps, 3)
+        # every nn.Linear is one bracket per pass: qkv, proj, fc1(+GELU), fc2 per block + decoder_embed = 4 * depth + 1 (round 2's
+        # timer counted fc1 twice: ops.linear_gelu calls ops.linear_fwd)
+        want = (4 * len(model.blocks) + 1) * args.profile_steps
+        for fam in ("gemm256_fwd", "gemm256_dgrad", "gemm256_wgrad"):
+            assert kernels[fam]["launches"] == want, (fam, kernels[fam]["launches"], want)
 
     if rank == 0:
         ips = n_ranks * args.batch * args.steps / dt
@@ -333,7 +398,7 @@ def main():
             dominant = dict(kernels[dk], family=dk)
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC passes (tools/pmc_traffic.py), bytes per launch
-        if os.path.exists(tpath) and dominant is not None:
+        if os.path.exists(tpath) and dominant is not None and args.model == "vit_large":
             try:
                 tj = json.load(open(tpath))
                 key = {"gemm256_fwd": "fc1", "gemm256_wgrad": "wgrad", "gemm256_dgrad": "dgrad", "attention_fwd": "attn_fwd",
@@ -341,27 +406,29 @@ def main():
                 traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        achieved = ips / n_ranks * FLOP_BLOCKS_FWD_BWD / 1e12
+        achieved = ips / n_ranks * spec["blocks"] / 1e12
         out = {
-            "metric": "images/sec (896x448 pairs) ViT-L fwd+bwd",
+            "metric": "images/sec (896x448 pairs) %s fwd+bwd" % ("ViT-L" if args.model == "vit_large" else "ViT-H/14"),
             "value": round(ips, 3), "unit": "images/sec", "n_gpus": n_ranks, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "painter_vit_large_patch16_input896x448 %s batch=%d/GPU fwd+bwd on %dxMI355X (BASELINE configs[1])"
-                                   % (args.dtype, args.batch, n_ranks),
+            "config": {"workload": spec["workload"] % (args.dtype, args.batch, n_ranks),
                        "global_batch": n_ranks * args.batch, "image": "896x448x3 stitched pair", "tokens": cfg.L,
                        "mode": "eval" if args.eval else "train (DropPath 0.1)", "parallelism": "dp%d" % n_ranks,
                        "rccl_ranks": n_ranks if distributed else 0,
                        "grad_allreduce": "RCCL bucketed, overlapped with backward" if n_ranks > 1 else "n/a"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "definition": "images/s/GPU x 4.034 TFLOP (attention + MLP blocks, fwd+bwd; SURVEY.md 8d) / dense bf16 MFMA peak",
-                         "whole_model_achieved": round(ips / n_ranks * FLOP_MODEL_FWD_BWD / 1e12, 2),
-                         "whole_model_frac": round(ips / n_ranks * FLOP_MODEL_FWD_BWD / 1e12 / peak, 4),
-                         "traffic": traffic, "dominant_kernel": dominant, "kernels": kernels,
+                         "definition": "images/s/GPU x %.3f TFLOP (attention + MLP blocks, fwd+bwd; SURVEY.md 8d) / dense bf16 MFMA peak" % (spec["blocks"] / 1e12),
+                         "whole_model_achieved": round(ips / n_ranks * spec["whole"] / 1e12, 2),
+                         "whole_model_frac": round(ips / n_ranks * spec["whole"] / 1e12 / peak, 4),
+                         "traffic": traffic, "traffic_source": "profiles/roofline_traffic.json (rocprofv3 PMC passes of this bench, tools/pmc_traffic.py; not re-measured inside this run)" if traffic is not None else None,
+                         "dominant_kernel": dominant, "kernels": kernels,
                          "profiled_pass": "separate pass of %d steps after the timed region, HIP events per launch, one stream" % args.profile_steps},
             "loss": round(lossv, 6),
+            "sustained": sustained,
+            "build": {"git_head": os.environ.get("PAINTER_AMD_GIT_HEAD"), "lib_sha16": _lib_sha16()},
         }
-        if n_ranks == 1 and args.dtype == "bf16" and not args.no_optimizer:
+        if n_ranks == 1 and args.dtype == "bf16" and not args.no_optimizer and args.model == "vit_large":
             out["optimizer_step"] = optimizer_step_ms(model, step)
         if n_ranks == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

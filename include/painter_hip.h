@@ -79,13 +79,15 @@ int pa_layernorm_bwd(int dtype, const void* dy, int64_t lddy, const float* x, in
 
 /* ---- Attention with decomposed rel-pos bias: models_painter.py:76-86 + util/vitdet_utils.py:63-125 ---- */
 int pa_relpos_rows_padded(int Hp, int Wp);
-/* rcat: T [pa_relpos_rows_padded, 64] = [rel_pos_h ; rel_pos_w ; 0] */
-int pa_relpos_pack(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcat, int Hp, int Wp,
+/* head_dim (hd) = embed_dim / heads: 64 (every reference factory; all kernel generations) or 80 (ViT-H/14, BASELINE configs[4]: the
+ * generic kernels of csrc/attn_fwd.hip / attn_bwd.hip, both dtypes); anything else is rejected.
+ * rcat: T [pa_relpos_rows_padded, hd] = [rel_pos_h ; rel_pos_w ; 0] */
+int pa_relpos_pack(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcat, int Hp, int Wp, int head_dim,
                    hipStream_t stream);
-/* qkv: T [batch*L, 3*heads*64] as produced by the qkv Linear; out: T [batch*L, heads*64]; lse: f32 [batch*heads, L].
+/* qkv: T [batch*L, 3*heads*hd] as produced by the qkv Linear; out: T [batch*L, heads*hd]; lse: f32 [batch*heads, L].
  * tables: NULL (inference), or pa_attn_tables_bytes() of device memory that receives the per-query bias tables the
  * backward reuses (only the 28-token-wide bf16 kernels write it; the size is 0 for every other case). */
-int64_t pa_attn_tables_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp);
+int64_t pa_attn_tables_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp, int head_dim);
 /* 0 = default kernels for the grid (generation 3 where it applies), 3 = the same explicitly, 2 = never use the 28-token-wide
  * generation-3 kernels (diagnostics, A/B, cross-generation tests) */
 int pa_attn_set_generation(int generation);
@@ -93,7 +95,7 @@ int pa_attn_set_generation(int generation);
  * host_out (may be NULL) receives the 2 x 2 x 64 x 8 stamps of the last traced launch */
 int pa_attn_trace(int enable, unsigned long long* host_out);
 int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse,
-                void* tables, int batch, int L, int heads, int Hp, int Wp, float scale, hipStream_t stream);
+                void* tables, int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t stream);
 
 /* autograd of pa_attn_fwd (no reference source: torch autograd of the lines above).
  *   delta  : f32 [batch*heads, L] = rowsum(dO o O)                      (pa_attn_bwd_delta)
@@ -102,26 +104,29 @@ int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void*
  *   aux    : scratch of pa_attn_bwd_aux_bytes()
  *   tables : what pa_attn_fwd wrote (NULL: the backward recomputes the bias tables itself, generation-2 kernels);
  *            the backward adds lse / delta fields to it
- *   rcatT  : T [64, NRP] from pa_relpos_pack_t
- *   drcat  : f32 [NRP, 64] = [d rel_pos_h ; d rel_pos_w ; 0], overwritten */
-int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcatT, int Hp, int Wp,
+ *   rcatT  : T [hd, NRP] from pa_relpos_pack_t
+ *   drcat  : f32 [NRP, hd] = [d rel_pos_h ; d rel_pos_w ; 0], overwritten */
+int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcatT, int Hp, int Wp, int head_dim,
                      hipStream_t stream);
 int pa_attn_bwd_delta(int dtype, const void* out, int64_t ldo, const void* dout, int64_t lddo, float* delta, int batch,
-                      int L, int heads, hipStream_t stream);
+                      int L, int heads, int head_dim, hipStream_t stream);
 int64_t pa_attn_bwd_aux_bytes(int batch, int L, int heads, int Hp, int Wp);
 int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, const void* rcatT, const void* dout,
                 int64_t lddo, const float* lse, const float* delta, void* dqkv, void* dG, void* aux, void* tables,
-                int batch, int L, int heads, int Hp, int Wp, float scale, hipStream_t stream);
-int64_t pa_attn_bwd_relpos_workspace_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp);
+                int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t stream);
+int64_t pa_attn_bwd_relpos_workspace_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp, int head_dim);
 int pa_attn_bwd_relpos(int dtype, const void* dG, const void* qkv, int64_t ldq, float* drcat, void* workspace,
-                       int batch, int L, int heads, int Hp, int Wp, hipStream_t stream);
+                       int batch, int L, int heads, int Hp, int Wp, int head_dim, hipStream_t stream);
 
 /* ---- PatchEmbed (Conv2d k=P s=P as an im2col GEMM) + token assembly: util/vitdet_utils.py:182-186,
  *      models_painter.py:387-409 (mask token, segment tokens, abs pos), models_seggpt.py:415-420 (type tokens) ----
- * imgs/tgts: f32 NCHW [B,3,Hp*P,Wp*P]; w: T [D, 3*P*P]; pos: f32 [L, D] from pa_pos_fwd; mask: bool bytes [B or 1, L];
+ * imgs/tgts: f32 NCHW [B,3,Hp*P,Wp*P]; w: T [D, ldw], ldw >= Kp = 3*P*P rounded up to 8, columns >= 3*P*P zero (pa_patch_weight_pack
+ * makes it from the conv weight; for P % 8 == 0 it is the plain T copy with ldw = 3*P*P); any P >= 1 (P = 14: ViT-H/14);
+ * pos: f32 [L, D] from pa_pos_fwd; mask: bool bytes [B or 1, L];
  * type_cls/type_ins/seg_type: SegGPT only (NULL otherwise), seg_type f32 [B];
  * tokens: f32 [2*B*L, D] = cat(x stream, y stream) on the batch axis (models_painter.py:409). */
-int pa_patch_embed_fwd(int dtype, const float* imgs, const float* tgts, const void* w, const float* bias,
+int pa_patch_weight_pack(int dtype, const float* w /*f32 [D, 3*P*P]*/, void* out /*T [D, Kp]*/, int D, int P, hipStream_t stream);
+int pa_patch_embed_fwd(int dtype, const float* imgs, const float* tgts, const void* w, int64_t ldw, const float* bias,
                        const float* mask_token, const float* seg_x, const float* seg_y, const float* pos,
                        const unsigned char* mask, int mask_batch_stride, const float* type_cls, const float* type_ins,
                        const float* seg_type, float* tokens, int batch, int Hp, int Wp, int P, int D, hipStream_t stream);

@@ -386,6 +386,27 @@ def small_config(seggpt: bool = False) -> OracleConfig:
     return OracleConfig(img_size=(128, 64), embed_dim=128, depth=24, num_heads=2, decoder_embed_dim=64, seggpt=seggpt)
 
 
+def generalised_taps(depth: int) -> Tuple[int, ...]:
+    """depth/4*k - 1: the reference's [5, 11, 17, 23] (models_painter.py:416) at depth 24, extended to other depths (SURVEY.md 8d note H:
+    with the hard-coded list a depth-32 model would leave blocks 24-31 without gradient)."""
+    return tuple(depth // 4 * k - 1 for k in range(1, 5))
+
+
+def h14_small_config(depth: int = 16) -> OracleConfig:
+    """Smallest ViT-H/14-shaped case the HIP path takes: patch 14, head_dim 80 (embed 160 / 2 heads), 8 x 4 tokens, the 16 x 16
+    pre-training position grid.  depth 24 = the configuration the unmodified reference can run (tests/golden/painter_h14.npz);
+    other depths use the generalised taps."""
+    return OracleConfig(img_size=(112, 56), patch_size=14, embed_dim=160, depth=depth, num_heads=2, decoder_embed_dim=64,
+                        taps=generalised_taps(depth))
+
+
+def vit_huge_config() -> OracleConfig:
+    """BASELINE configs[4] / SURVEY.md 8d config 5: ViT-H/14 through the class constructor (models_painter.py:241-266) -- patch 14,
+    embed 1280, depth 32, 16 heads (head_dim 80), 64 x 32 tokens.  NOT a reference factory; taps generalised."""
+    return OracleConfig(img_size=(896, 448), patch_size=14, embed_dim=1280, depth=32, num_heads=16, decoder_embed_dim=64,
+                        taps=generalised_taps(32))
+
+
 def vit_large_config(seggpt: bool = False) -> OracleConfig:
     """Painter/models_painter.py:476-487 / models_seggpt.py:483-494."""
     return OracleConfig(seggpt=seggpt)

@@ -18,66 +18,80 @@
 #include "attn3.h"
 
 // ------------------------------------------------------------------------------- Delta pre-pass
-template <typename T> __global__ void attn_delta_kernel(const T* o, size_t ldo, const T* d_o, size_t lddo, float* delta, int R, int L, int H) {
+// one wave per row; a group of GL = hd / 16 consecutive lanes covers one head (16 elements per lane)
+template <typename T> __global__ void attn_delta_kernel(const T* o, size_t ldo, const T* d_o, size_t lddo, float* delta, int R, int L, int H, int hd) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= R) return;
     const int b = row / L, l = row % L;
-    const int D = H * ATT_HD;
-    for (int c = lane * 16; c < D; c += 1024) {
-        float s = 0.f;
+    const int D = H * hd;
+    if (hd == 64) {
+        for (int c = lane * 16; c < D; c += 1024) {
+            float s = 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s += to_f(o[(size_t)row * ldo + c + e]) * to_f(d_o[(size_t)row * lddo + c + e]);
-        s = quad_sum(s);
-        if ((lane & 3) == 0) delta[((size_t)b * H + c / ATT_HD) * L + l] = s;
+            for (int e = 0; e < 16; ++e) s += to_f(o[(size_t)row * ldo + c + e]) * to_f(d_o[(size_t)row * lddo + c + e]);
+            s = quad_sum(s);
+            if ((lane & 3) == 0) delta[((size_t)b * H + c / 64) * L + l] = s;
+        }
+    } else {                                    // any hd % 16 == 0: one lane per head (not on a timed path: fixed summation order, no exchange)
+        for (int h = lane; h < H; h += 64) {
+            float s = 0.f;
+            for (int e = 0; e < hd; ++e) s += to_f(o[(size_t)row * ldo + h * hd + e]) * to_f(d_o[(size_t)row * lddo + h * hd + e]);
+            delta[((size_t)b * H + h) * L + l] = s;
+        }
     }
 }
 extern "C" int pa_attn_bwd_delta(int dtype, const void* out, int64_t ldo, const void* dout, int64_t lddo, float* delta, int batch, int L,
-                                 int heads, hipStream_t st) {
+                                 int heads, int head_dim, hipStream_t st) {
+    if (head_dim <= 0 || head_dim % 16) return (int)hipErrorInvalidValue;
     const int R = batch * L;
     if (dtype == PA_BF16)
-        PA_LAUNCH(attn_delta_kernel<bf16>, dim3((R + 3) / 4), dim3(256), 0, st, (const bf16*)out, (size_t)ldo, (const bf16*)dout, (size_t)lddo, delta, R, L, heads);
+        PA_LAUNCH(attn_delta_kernel<bf16>, dim3((R + 3) / 4), dim3(256), 0, st, (const bf16*)out, (size_t)ldo, (const bf16*)dout, (size_t)lddo, delta, R, L, heads, head_dim);
     else
-        PA_LAUNCH(attn_delta_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, st, (const float*)out, (size_t)ldo, (const float*)dout, (size_t)lddo, delta, R, L, heads);
+        PA_LAUNCH(attn_delta_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, st, (const float*)out, (size_t)ldo, (const float*)dout, (size_t)lddo, delta, R, L, heads, head_dim);
     LAUNCH_CHECK();
 }
 
 // ------------------------------------------------------------------------------- kernel A: dQ + bias-gradient tables
-template <typename T, int NW>
+template <typename T, int NW, int HD>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const T* __restrict__ qkv, size_t ldq, const T* __restrict__ rcat,
                                                               const T* __restrict__ rcatT, const T* __restrict__ dout, size_t lddo,
                                                               const float* __restrict__ lse, const float* __restrict__ delta,
                                                               T* __restrict__ dqkv, T* __restrict__ dG, float* __restrict__ aux, int L,
                                                               int H, int Hp, int Wp, int NRP, float scale, int tab_stride) {
+    typedef KvTile<T, HD> KV;
     constexpr int NT = NW * 64;
-    constexpr int KVB = KvTile<T>::BYTES;
+    constexpr int KB = KV::KB, VB = KV::VB, KS = KV::KS, DB = KV::DB;
+    constexpr int STG = 2 * KB + VB;           // one stage: K row image, V row image, K^T image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const int D = H * ATT_HD, TS = Hp + Wp;
-    const T* base = qkv + (size_t)b * L * ldq + h * ATT_HD;
+    const int D = H * HD, TS = Hp + Wp;
+    const T* base = qkv + (size_t)b * L * ldq + h * HD;
     const T* kbase = base + D;
     const T* vbase = base + 2 * D;
     const int qt = blockIdx.x * NW + wave;
     const bool valid = qt * 32 < L;
     const int q = qt * 32 + (lane & 31);
     const int qh = q / Wp, qw = q % Wp;
-    // LDS: stage s in {0,1}: K row image, K^T image, V row image; then per-wave [bias table | grad table]
-    unsigned char* wreg = smem + 6 * KVB + (size_t)wave * tab_stride;
+    // LDS: stage s in {0,1}: K row image, V row image, K^T image; then per-wave [bias table | grad table]
+    unsigned char* wreg = smem + 2 * STG + (size_t)wave * tab_stride;
+    KV::zero_pad(smem + 2 * KB, tid, NT);
+    KV::zero_pad(smem + STG + 2 * KB, tid, NT);
     float* tab = reinterpret_cast<float*>(wreg) + (lane & 31) * TS;
     float* tabg = reinterpret_cast<float*>(wreg) + 32 * TS + (lane & 31) * TS;
 
-    Frag<T> qf[4], dof[4];
+    Frag<T> qf[KS], dof[KS];
     float lse2 = 0.f, dlt = 0.f;
     if (valid) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < KS; ++s) {
             load_gfrag<T>(qf[s], base + (size_t)q * ldq, s, g);
-            load_gfrag<T>(dof[s], dout + (size_t)(b * L + q) * lddo + h * ATT_HD, s, g);
+            load_gfrag<T>(dof[s], dout + (size_t)(b * L + q) * lddo + h * HD, s, g);
         }
         lse2 = lse[(size_t)bh * L + q] * LOG2E_F;
         dlt = delta[(size_t)bh * L + q];
-        build_bias_table<T>(tab, rcat, NRP, qf, qh, qw, Hp, Wp, lane);
+        build_bias_table<T, HD>(tab, rcat, NRP, qf, qh, qw, Hp, Wp, lane);
         for (int c = g; c < TS; c += 2) tabg[c] = 0.f;
         // export the transposed table + per-row scalars for kernel B
         float* ax = aux + ((size_t)bh * (L / 32) + qt) * (TS + 2) * 32 + (lane & 31);
@@ -86,20 +100,22 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const T* __restric
         else ax[(size_t)(TS + 1) * 32] = dlt;
     }
 
-    RowStage<T, NT> ks, vs;
-    TrStage<T> kts;
+    RowStage<T, NT, HD> ks, vs;
+    TrStage<T, HD> kts;
     const int ntile = L / 32;
     ks.load(kbase, ldq, tid);
     kts.load(kbase, ldq, tid);
     vs.load(vbase, ldq, tid);
     ks.store(smem, tid);
-    kts.store(smem + KVB, tid);
-    vs.store(smem + 2 * KVB, tid);
+    vs.store(smem + KB, tid);
+    kts.store(smem + 2 * KB, tid);
     __syncthreads();
 
-    f32x16 dq[2];
+    f32x16 dq[DB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dq[0][r] = 0.f; dq[1][r] = 0.f; }
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[db][r] = 0.f;
     const float sl = scale * LOG2E_F;
     int kh[4], kw[4];
 #pragma unroll
@@ -117,16 +133,16 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const T* __restric
             kts.load(kp, ldq, tid);
             vs.load(vbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
         }
-        const unsigned char* st = smem + (j & 1) * 3 * KVB;
+        const unsigned char* st = smem + (j & 1) * STG;
         if (valid) {
             f32x16 sacc, dpacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 Frag<T> kf, vf;
-                load_rowfrag<T>(kf, st, lane & 31, s, g);
-                load_rowfrag<T>(vf, st + 2 * KVB, lane & 31, s, g);
+                load_rowfrag<T, HD>(kf, st, lane & 31, s, g);
+                load_rowfrag<T, HD>(vf, st + KB, lane & 31, s, g);
                 mma(sacc, kf, qf[s]);
                 mma(dpacc, vf, dof[s]);
             }
@@ -158,11 +174,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const T* __restric
             pack_frag<T>(dsf[0], ds);
             pack_frag<T>(dsf[1], ds + 8);
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     Frag<T> ktf;
-                    load_trfrag<T>(ktf, st + KVB, db * 32 + (lane & 31), s, g);
+                    load_trfrag<T, HD>(ktf, st + 2 * KB, db * 32 + (lane & 31), s, g);
                     mma(dq[db], ktf, dsf[s]);
                 }
 #pragma unroll
@@ -173,19 +189,21 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const T* __restric
             }
         }
         if (j + 1 < ntile) {
-            unsigned char* sn = smem + ((j + 1) & 1) * 3 * KVB;
+            unsigned char* sn = smem + ((j + 1) & 1) * STG;
             ks.store(sn, tid);
-            kts.store(sn + KVB, tid);
-            vs.store(sn + 2 * KVB, tid);
+            vs.store(sn + KB, tid);
+            kts.store(sn + 2 * KB, tid);
         }
         __syncthreads();
     }
 
     // bias part of dQ through r-space: dQ^T[d][q] = scale * acc + sum_r Rcat[r][d] dG[q][r]; also emit dG (T)
-    constexpr int ROWB = ATT_HD * sizeof(T);
+    constexpr int ROWB = HD * sizeof(T);
     if (valid) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dq[0][r] *= scale; dq[1][r] *= scale; }
+        for (int db = 0; db < DB; ++db)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dq[db][r] *= scale;
         T* dgrow = dG + ((size_t)(b * L + q) * H + h) * NRP;
         for (int s = 0; s < NRP / 16; ++s) {
             float gv[8];
@@ -212,11 +230,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const T* __restric
                 *reinterpret_cast<float4*>(dgrow + 16 * s + 8 * g + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
             }
 #pragma unroll
-            for (int db = 0; db < 2; ++db) {
+            for (int db = 0; db < DB; ++db) {
                 Frag<T> rf;
-                const T* rp = rcatT + (size_t)(db * 32 + (lane & 31)) * NRP + 16 * s + 8 * g;
-                if constexpr (sizeof(T) == 2) rf.set(*reinterpret_cast<const uint4*>(rp));
-                else rf.set(*reinterpret_cast<const uint4*>(rp), *reinterpret_cast<const uint4*>(rp + 4));
+                const int dr = db * 32 + (lane & 31);                                  // rows d >= HD of the last block: zero operand
+                const T* rp = rcatT + (size_t)(dr < HD ? dr : 0) * NRP + 16 * s + 8 * g;
+                if constexpr (sizeof(T) == 2) rf.set(dr < HD ? *reinterpret_cast<const uint4*>(rp) : zero4());
+                else rf.set(dr < HD ? *reinterpret_cast<const uint4*>(rp) : zero4(), dr < HD ? *reinterpret_cast<const uint4*>(rp + 4) : zero4());
                 mma(dq[db], rf, gf);
             }
         }
@@ -224,13 +243,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const T* __restric
     __syncthreads();      // every wave is done with its tables -> reuse the region as the dQ staging tile
     if (valid) {
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int d0 = db * 32 + 8 * rg + 4 * g;
-                T* dst = reinterpret_cast<T*>(wreg + (lane & 31) * ROWB) + d0;
-                *reinterpret_cast<typename TT<T>::Vec4*>(dst) =
-                    cvt4(dq[db][rg * 4], dq[db][rg * 4 + 1], dq[db][rg * 4 + 2], dq[db][rg * 4 + 3], (T*)nullptr);
+                if (d0 < HD) {
+                    T* dst = reinterpret_cast<T*>(wreg + (lane & 31) * ROWB) + d0;
+                    *reinterpret_cast<typename TT<T>::Vec4*>(dst) =
+                        cvt4(dq[db][rg * 4], dq[db][rg * 4 + 1], dq[db][rg * 4 + 2], dq[db][rg * 4 + 3], (T*)nullptr);
+                }
             }
     }
     __syncthreads();
@@ -240,42 +261,43 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dq_kernel(const T* __restric
         for (int i = 0; i < 32 * CPR / 64; ++i) {
             const int c = lane + 64 * i, row = c / CPR, ch = c % CPR;
             const uint4 v = *reinterpret_cast<const uint4*>(wreg + row * ROWB + ch * 16);
-            *reinterpret_cast<uint4*>(dqkv + (size_t)(b * L + qt * 32 + row) * ldq + h * ATT_HD + ch * TT<T>::EPC) = v;
+            *reinterpret_cast<uint4*>(dqkv + (size_t)(b * L + qt * 32 + row) * ldq + h * HD + ch * TT<T>::EPC) = v;
         }
     }
 }
 
 // ------------------------------------------------------------------------------- kernel B: dK, dV
 #define AUX_LD 36   // floats per LDS row of the transposed aux tile (32 + 4 pad: conflict-free 16-B reads)
-template <typename T, int NW>
+template <typename T, int NW, int HD>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const T* __restrict__ qkv, size_t ldq, const T* __restrict__ dout,
                                                                size_t lddo, const float* __restrict__ aux, T* __restrict__ dqkv, int L,
                                                                int H, int Hp, int Wp, float scale) {
+    typedef KvTile<T, HD> KV;
     constexpr int NT = NW * 64;
-    constexpr int KVB = KvTile<T>::BYTES;
+    constexpr int KB = KV::KB, VB = KV::VB, KS = KV::KS, DB = KV::DB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const int D = H * ATT_HD, TS = Hp + Wp;
+    const int D = H * HD, TS = Hp + Wp;
     const int AUXB = (TS + 2) * AUX_LD * 4;
-    const int STG = 4 * KVB + AUXB;            // Q row, Q^T, dO row, dO^T, aux
-    const T* qbase = qkv + (size_t)b * L * ldq + h * ATT_HD;
-    const T* dobase = dout + (size_t)b * L * lddo + h * ATT_HD;
+    const int STG = 2 * KB + 2 * VB + AUXB;    // Q row, dO row, Q^T, dO^T, aux
+    const T* qbase = qkv + (size_t)b * L * ldq + h * HD;
+    const T* dobase = dout + (size_t)b * L * lddo + h * HD;
     const int kt = blockIdx.x * NW + wave;
     const bool valid = kt * 32 < L;
     const int key = kt * 32 + (lane & 31);
     const int khl = key / Wp, kwl = key % Wp;
 
-    Frag<T> kf[4], vf[4];
+    Frag<T> kf[KS], vf[KS];
     if (valid) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < KS; ++s) {
             load_gfrag<T>(kf[s], qbase + D + (size_t)key * ldq, s, g);
             load_gfrag<T>(vf[s], qbase + 2 * D + (size_t)key * ldq, s, g);
         }
     }
-    RowStage<T, NT> qs, dos;
-    TrStage<T> qts, dots;
+    RowStage<T, NT, HD> qs, dos;
+    TrStage<T, HD> qts, dots;
     const int NAUX = (TS + 2) * 8;                       // 16-B chunks of the aux tile
     constexpr int CAUX = 3;                              // up to 3 * NT chunks (TS + 2 <= 3 * NT / 8)
     uint4 ra[CAUX];
@@ -295,22 +317,28 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const T* __restri
     auto store_all = [&](int stage) {
         unsigned char* s0 = smem + stage * STG;
         qs.store(s0, tid);
-        qts.store(s0 + KVB, tid);
-        dos.store(s0 + 2 * KVB, tid);
-        dots.store(s0 + 3 * KVB, tid);
+        dos.store(s0 + KB, tid);
+        qts.store(s0 + 2 * KB, tid);
+        dots.store(s0 + 2 * KB + VB, tid);
 #pragma unroll
         for (int i = 0; i < CAUX; ++i) {
             const int c = tid + NT * i;
-            if (c < NAUX) *reinterpret_cast<uint4*>(s0 + 4 * KVB + (c >> 3) * (AUX_LD * 4) + (c & 7) * 16) = ra[i];
+            if (c < NAUX) *reinterpret_cast<uint4*>(s0 + 2 * KB + 2 * VB + (c >> 3) * (AUX_LD * 4) + (c & 7) * 16) = ra[i];
         }
     };
+    for (int stage = 0; stage < 2; ++stage) {
+        KV::zero_pad(smem + stage * STG + 2 * KB, tid, NT);
+        KV::zero_pad(smem + stage * STG + 2 * KB + VB, tid, NT);
+    }
     load_all(0);
     store_all(0);
     __syncthreads();
 
-    f32x16 dk[2], dv[2];
+    f32x16 dk[DB], dv[DB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dk[0][r] = 0.f; dk[1][r] = 0.f; dv[0][r] = 0.f; dv[1][r] = 0.f; }
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dk[db][r] = 0.f; dv[db][r] = 0.f; }
     const float sl = scale * LOG2E_F;
 
     for (int j = 0; j < ntile; ++j) {
@@ -321,14 +349,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const T* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; dpacc[r] = 0.f; }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 Frag<T> qf, dof;
-                load_rowfrag<T>(qf, st, lane & 31, s, g);
-                load_rowfrag<T>(dof, st + 2 * KVB, lane & 31, s, g);
+                load_rowfrag<T, HD>(qf, st, lane & 31, s, g);
+                load_rowfrag<T, HD>(dof, st + KB, lane & 31, s, g);
                 mma(sacc, qf, kf[s]);          // S[q][key]: lane = key, regs = q rows
                 mma(dpacc, dof, vf[s]);        // dP[q][key]
             }
-            const float* ax = reinterpret_cast<const float*>(st + 4 * KVB);
+            const float* ax = reinterpret_cast<const float*>(st + 2 * KB + 2 * VB);
             float p[16], ds[16];
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
@@ -352,12 +380,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const T* __restri
             pack_frag<T>(dsf[0], ds);
             pack_frag<T>(dsf[1], ds + 8);
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     Frag<T> qtf, dotf;
-                    load_trfrag<T>(dotf, st + 3 * KVB, db * 32 + (lane & 31), s, g);
-                    load_trfrag<T>(qtf, st + KVB, db * 32 + (lane & 31), s, g);
+                    load_trfrag<T, HD>(dotf, st + 2 * KB + VB, db * 32 + (lane & 31), s, g);
+                    load_trfrag<T, HD>(qtf, st + 2 * KB, db * 32 + (lane & 31), s, g);
                     mma(dv[db], dotf, pf[s]);      // dV^T[d][key] += dO^T[d][q] P[q][key]
                     mma(dk[db], qtf, dsf[s]);      // dK^T[d][key] += Q^T[d][q] dS[q][key]
                 }
@@ -367,14 +395,15 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const T* __restri
     }
 
     // store dK (x scale) and dV rows through a per-wave LDS staging tile
-    constexpr int ROWB = ATT_HD * sizeof(T);
+    constexpr int ROWB = HD * sizeof(T);
     unsigned char* stg = smem + (size_t)wave * 2 * 32 * ROWB;
     if (valid) {
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int d0 = db * 32 + 8 * rg + 4 * g;
+                if (d0 >= HD) continue;
                 T* dstk = reinterpret_cast<T*>(stg + (lane & 31) * ROWB) + d0;
                 T* dstv = reinterpret_cast<T*>(stg + 32 * ROWB + (lane & 31) * ROWB) + d0;
                 *reinterpret_cast<typename TT<T>::Vec4*>(dstk) = cvt4(dk[db][rg * 4] * scale, dk[db][rg * 4 + 1] * scale,
@@ -389,7 +418,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const T* __restri
 #pragma unroll
         for (int i = 0; i < 32 * CPR / 64; ++i) {
             const int c = lane + 64 * i, row = c / CPR, ch = c % CPR;
-            T* orow = dqkv + (size_t)(b * L + kt * 32 + row) * ldq + h * ATT_HD + ch * TT<T>::EPC;
+            T* orow = dqkv + (size_t)(b * L + kt * 32 + row) * ldq + h * HD + ch * TT<T>::EPC;
             *reinterpret_cast<uint4*>(orow + D) = *reinterpret_cast<const uint4*>(stg + row * ROWB + ch * 16);
             *reinterpret_cast<uint4*>(orow + 2 * D) = *reinterpret_cast<const uint4*>(stg + 32 * ROWB + row * ROWB + ch * 16);
         }
@@ -398,23 +427,25 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const T* __restri
 
 // ------------------------------------------------------------------------------- host side
 // RcatT[d][r] (T) -- the transposed operand of the dQ bias contraction
-template <typename T> __global__ void relpos_pack_t_kernel(const float* rh, int nh, const float* rw, int nw, T* out, int NRP) {
+template <typename T> __global__ void relpos_pack_t_kernel(const float* rh, int nh, const float* rw, int nw, T* out, int NRP, int hd) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NRP * ATT_HD) return;
+    if (i >= NRP * hd) return;
     const int d = i / NRP, r = i % NRP;
     float v = 0.f;
-    if (r < nh) v = rh[r * ATT_HD + d];
-    else if (r - nh < nw) v = rw[(r - nh) * ATT_HD + d];
+    if (r < nh) v = rh[r * hd + d];
+    else if (r - nh < nw) v = rw[(r - nh) * hd + d];
     out[i] = from_f<T>(v);
 }
 extern "C" int pa_relpos_rows_padded(int Hp, int Wp);
-extern "C" int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcatT, int Hp, int Wp, hipStream_t st) {
+extern "C" int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcatT, int Hp, int Wp, int head_dim,
+                                hipStream_t st) {
+    if (head_dim <= 0 || head_dim % 16) return (int)hipErrorInvalidValue;
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
-    const int n = NRP * ATT_HD;
+    const int n = NRP * head_dim;
     if (dtype == PA_BF16)
-        PA_LAUNCH(relpos_pack_t_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (bf16*)rcatT, NRP);
+        PA_LAUNCH(relpos_pack_t_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (bf16*)rcatT, NRP, head_dim);
     else
-        PA_LAUNCH(relpos_pack_t_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (float*)rcatT, NRP);
+        PA_LAUNCH(relpos_pack_t_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (float*)rcatT, NRP, head_dim);
     LAUNCH_CHECK();
 }
 
@@ -424,41 +455,53 @@ extern "C" int64_t pa_attn_bwd_aux_bytes(int batch, int L, int heads, int Hp, in
     return gen1 > gen2 ? gen1 : gen2;
 }
 
-template <typename T>
+template <typename T, int NW, int HD>
+static int attn_bwd_dq_launch(const T* qkv, int64_t ldq, const T* rcat, const T* rcatT, const T* dout, int64_t lddo, const float* lse,
+                              const float* delta, T* dqkv, T* dG, float* aux, int Bn, int L, int H, int Hp, int Wp, float scale, size_t smem,
+                              int ts, hipStream_t st) {
+    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    auto kern = attn_bwd_dq_kernel<T, NW, HD>;
+    static bool done = false;
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    const int qtiles = L / 32;
+    PA_LAUNCH(kern, dim3((qtiles + NW - 1) / NW, Bn * H), dim3(NW * 64), smem, st, qkv, (size_t)ldq, rcat, rcatT, dout,
+              (size_t)lddo, lse, delta, dqkv, dG, aux, L, H, Hp, Wp, NRP, scale, ts);
+    return (int)hipGetLastError();
+}
+
+template <typename T, int HD>
 static int attn_bwd_t(const T* qkv, int64_t ldq, const T* rcat, const T* rcatT, const T* dout, int64_t lddo, const float* lse,
                       const float* delta, T* dqkv, T* dG, float* aux, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st) {
-    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    typedef KvTile<T, HD> KV;
     const int TS = Hp + Wp;
-    constexpr int KVB = KvTile<T>::BYTES;
     const int qtiles = L / 32;
-    {   // kernel A
-        constexpr int NW = 4;
+    {   // kernel A: 4 waves per workgroup where the per-wave tables fit the LDS beside the staging images, otherwise 2
         int ts = 2 * 32 * TS * 4;
-        const int stg = 32 * ATT_HD * (int)sizeof(T);
+        const int stg = 32 * HD * (int)sizeof(T);
         if (ts < stg) ts = stg;
         ts = (ts + 15) / 16 * 16;
-        const size_t smem = 6 * KVB + (size_t)NW * ts;
-        if (smem > 160 * 1024) return (int)hipErrorInvalidValue;
-        auto kern = attn_bwd_dq_kernel<T, NW>;
-        static bool done = false;
-        if (!done) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return (int)e;
-            done = true;
+        const size_t stages = 2 * (size_t)(2 * KV::KB + KV::VB);
+        int e = (int)hipErrorInvalidValue;
+        if (stages + 4 * (size_t)ts <= 160 * 1024) {
+            e = attn_bwd_dq_launch<T, 4, HD>(qkv, ldq, rcat, rcatT, dout, lddo, lse, delta, dqkv, dG, aux, Bn, L, H, Hp, Wp, scale, stages + 4 * (size_t)ts, ts, st);
+        } else if constexpr (HD != 64) {      // 3 waves x 64 threads >= 2 * HD, as TrStage needs (HD = 64 keeps its round-1 instantiation only)
+            if (stages + 3 * (size_t)ts <= 160 * 1024)
+                e = attn_bwd_dq_launch<T, 3, HD>(qkv, ldq, rcat, rcatT, dout, lddo, lse, delta, dqkv, dG, aux, Bn, L, H, Hp, Wp, scale, stages + 3 * (size_t)ts, ts, st);
         }
-        PA_LAUNCH(kern, dim3((qtiles + NW - 1) / NW, Bn * H), dim3(NW * 64), smem, st, qkv, (size_t)ldq, rcat, rcatT, dout,
-                           (size_t)lddo, lse, delta, dqkv, dG, aux, L, H, Hp, Wp, NRP, scale, ts);
-        int e = (int)hipGetLastError();
         if (e) return e;
     }
     {   // kernel B
         constexpr int NW = 4;
         const int AUXB = (TS + 2) * AUX_LD * 4;
-        size_t smem = 2 * (size_t)(4 * KVB + AUXB);
-        const size_t stg = (size_t)NW * 2 * 32 * ATT_HD * sizeof(T);
+        size_t smem = 2 * (size_t)(2 * KV::KB + 2 * KV::VB + AUXB);
+        const size_t stg = (size_t)NW * 2 * 32 * HD * sizeof(T);
         if (smem < stg) smem = stg;
         if (smem > 160 * 1024 || (TS + 2) * 8 > 3 * NW * 64) return (int)hipErrorInvalidValue;
-        auto kern = attn_bwd_dkv_kernel<T, NW>;
+        auto kern = attn_bwd_dkv_kernel<T, NW, HD>;
         static bool done = false;
         if (!done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -471,34 +514,34 @@ static int attn_bwd_t(const T* qkv, int64_t ldq, const T* rcat, const T* rcatT, 
     }
 }
 
-// dqkv: T [batch*L, 3*heads*64] (same layout as qkv); dG: T [batch*L, heads*NRP]; aux: pa_attn_bwd_aux_bytes scratch
+// dqkv: T [batch*L, 3*heads*hd] (same layout as qkv); dG: T [batch*L, heads*NRP]; aux: pa_attn_bwd_aux_bytes scratch
 extern "C" int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, const void* rcatT, const void* dout, int64_t lddo,
                            const float* lse, const float* delta, void* dqkv, void* dG, void* aux, void* tables, int batch, int L,
-                           int heads, int Hp, int Wp, float scale, hipStream_t st) {
-    if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4) return (int)hipErrorInvalidValue;
-    if (dtype == PA_BF16 && tables != nullptr && attn3_ok(L, Hp, Wp))
+                           int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t st) {
+    if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4 || (head_dim != 64 && head_dim != 80)) return (int)hipErrorInvalidValue;
+    if (dtype == PA_BF16 && head_dim == ATT_HD && tables != nullptr && attn3_ok(L, Hp, Wp))
         return attn3_bwd((const bf16*)qkv, ldq, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, tables, (bf16*)dqkv, (bf16*)dG,
                          batch, L, heads, Hp, Wp, scale, st);
-    if (dtype == PA_BF16 && attn2_ok(L, Hp, Wp))
+    if (dtype == PA_BF16 && head_dim == ATT_HD && attn2_ok(L, Hp, Wp))
         return attn2_bwd((const bf16*)qkv, ldq, (const bf16*)rcat, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, (bf16*)dqkv,
                          (bf16*)dG, aux, batch, L, heads, Hp, Wp, scale, st);
-    if (dtype == PA_BF16)
-        return attn_bwd_t<bf16>((const bf16*)qkv, ldq, (const bf16*)rcat, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta,
-                                (bf16*)dqkv, (bf16*)dG, (float*)aux, batch, L, heads, Hp, Wp, scale, st);
-    return attn_bwd_t<float>((const float*)qkv, ldq, (const float*)rcat, (const float*)rcatT, (const float*)dout, lddo, lse, delta,
-                             (float*)dqkv, (float*)dG, (float*)aux, batch, L, heads, Hp, Wp, scale, st);
+#define PA_ATTN_BWD(TT_, HD_) attn_bwd_t<TT_, HD_>((const TT_*)qkv, ldq, (const TT_*)rcat, (const TT_*)rcatT, (const TT_*)dout, lddo, lse, delta, \
+                                                   (TT_*)dqkv, (TT_*)dG, (float*)aux, batch, L, heads, Hp, Wp, scale, st)
+    if (dtype == PA_BF16) return head_dim == 80 ? PA_ATTN_BWD(bf16, 80) : PA_ATTN_BWD(bf16, 64);
+    return head_dim == 80 ? PA_ATTN_BWD(float, 80) : PA_ATTN_BWD(float, 64);
+#undef PA_ATTN_BWD
 }
 
-// d[rel_pos_h ; rel_pos_w ; pad][NRP, 64] (fp32) = sum over heads, samples, queries of dG[., r] * q[., d]
-extern "C" int64_t pa_attn_bwd_relpos_workspace_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp) {
+// d[rel_pos_h ; rel_pos_w ; pad][NRP, hd] (fp32) = sum over heads, samples, queries of dG[., r] * q[., d]
+extern "C" int64_t pa_attn_bwd_relpos_workspace_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp, int head_dim) {
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
-    return (int64_t)heads * 32 * NRP * ATT_HD * sizeof(float);
+    return (int64_t)heads * 32 * NRP * head_dim * sizeof(float);
 }
 template <typename T>
-static int relpos_grad_t(const T* dG, const T* qkv, int64_t ldq, float* drcat, float* ws, int Bn, int L, int H, int NRP, hipStream_t st) {
+static int relpos_grad_t(const T* dG, const T* qkv, int64_t ldq, float* drcat, float* ws, int Bn, int L, int H, int NRP, int hd, hipStream_t st) {
     const int R = Bn * L;
     OpT<T> A{dG, (size_t)H * NRP, NRP, (size_t)NRP};
-    OpT<T> B{qkv, (size_t)ldq, ATT_HD, (size_t)ATT_HD};
+    OpT<T> B{qkv, (size_t)ldq, hd, (size_t)hd};
     const int nku = (R + TT<T>::BK - 1) / TT<T>::BK;
     static const int want = [] { const char* v = getenv("PA_RELPOS_SPLITS"); return v ? atoi(v) : 16; }();      // 16: 45.7 us, 32: 52.6, 8: 67.9 (B=8)
     static const bool from_env = getenv("PA_RELPOS_SPLITS") != nullptr;
@@ -515,13 +558,14 @@ static int relpos_grad_t(const T* dG, const T* qkv, int64_t ldq, float* drcat, f
             });
         }
     };
-    int e = launch_gemm<T, 2, 2>(A, B, Epi{ws, (size_t)NRP * ATT_HD, NRP, ATT_HD}, NRP, ATT_HD, R, splits, H, st);
+    int e = launch_gemm<T, 2, 2>(A, B, Epi{ws, (size_t)NRP * hd, NRP, hd}, NRP, hd, R, splits, H, st);
     if (e) return e;
-    return pa_slab_reduce(ws, drcat, (int64_t)NRP * ATT_HD, splits * H, (int64_t)NRP * ATT_HD, 0, st);
+    return pa_slab_reduce(ws, drcat, (int64_t)NRP * hd, splits * H, (int64_t)NRP * hd, 0, st);
 }
 extern "C" int pa_attn_bwd_relpos(int dtype, const void* dG, const void* qkv, int64_t ldq, float* drcat, void* workspace, int batch, int L,
-                                  int heads, int Hp, int Wp, hipStream_t st) {
+                                  int heads, int Hp, int Wp, int head_dim, hipStream_t st) {
+    if (head_dim <= 0 || head_dim % 16) return (int)hipErrorInvalidValue;
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
-    if (dtype == PA_BF16) return relpos_grad_t<bf16>((const bf16*)dG, (const bf16*)qkv, ldq, drcat, (float*)workspace, batch, L, heads, NRP, st);
-    return relpos_grad_t<float>((const float*)dG, (const float*)qkv, ldq, drcat, (float*)workspace, batch, L, heads, NRP, st);
+    if (dtype == PA_BF16) return relpos_grad_t<bf16>((const bf16*)dG, (const bf16*)qkv, ldq, drcat, (float*)workspace, batch, L, heads, NRP, head_dim, st);
+    return relpos_grad_t<float>((const float*)dG, (const float*)qkv, ldq, drcat, (float*)workspace, batch, L, heads, NRP, head_dim, st);
 }

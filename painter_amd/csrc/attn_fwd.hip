@@ -14,43 +14,52 @@
 #include "attn2.h"
 #include "attn3.h"
 
-template <typename T, int NW>
+template <typename T, int NW, int HD>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__ qkv, size_t ldq, const T* __restrict__ rcat,
                                                            T* __restrict__ out, size_t ldo, float* __restrict__ lse, int L, int H,
                                                            int Hp, int Wp, int NRP, float scale, int tab_stride) {
+    typedef KvTile<T, HD> KV;
     constexpr int NT = NW * 64;
-    constexpr int KVB = KvTile<T>::BYTES;
+    constexpr int KB = KV::KB, VB = KV::VB, KS = KV::KS, DB = KV::DB;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
     const int bh = blockIdx.y, b = bh / H, h = bh % H;
-    const int D = H * ATT_HD, TS = Hp + Wp;
-    const T* base = qkv + (size_t)b * L * ldq + h * ATT_HD;
+    const int D = H * HD, TS = Hp + Wp;
+    const T* base = qkv + (size_t)b * L * ldq + h * HD;
     const T* kbase = base + D;
     const T* vbase = base + 2 * D;
     const int qt = blockIdx.x * NW + wave;
     const bool valid = qt * 32 < L;
     const int q = qt * 32 + (lane & 31);
-    float* tab = reinterpret_cast<float*>(smem + 4 * KVB + (size_t)wave * tab_stride) + (lane & 31) * TS;
+    // LDS: K row images [2 stages], V^T images [2 stages], then one table / output-staging region per wave
+    unsigned char* const kimg = smem;
+    unsigned char* const vimg = smem + 2 * KB;
+    unsigned char* const wreg = smem + 2 * KB + 2 * VB + (size_t)wave * tab_stride;
+    float* tab = reinterpret_cast<float*>(wreg) + (lane & 31) * TS;
+    KV::zero_pad(vimg, tid, NT);
+    KV::zero_pad(vimg + VB, tid, NT);
 
-    Frag<T> qf[4];
+    Frag<T> qf[KS];
     if (valid) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) load_gfrag<T>(qf[s], base + (size_t)q * ldq, s, g);
-        build_bias_table<T>(tab, rcat, NRP, qf, q / Wp, q % Wp, Hp, Wp, lane);
+        for (int s = 0; s < KS; ++s) load_gfrag<T>(qf[s], base + (size_t)q * ldq, s, g);
+        build_bias_table<T, HD>(tab, rcat, NRP, qf, q / Wp, q % Wp, Hp, Wp, lane);
     }
 
-    RowStage<T, NT> ks;
-    TrStage<T> vs;
+    RowStage<T, NT, HD> ks;
+    TrStage<T, HD> vs;
     const int ntile = L / 32;
     ks.load(kbase, ldq, tid);
     vs.load(vbase, ldq, tid);
-    ks.store(smem, tid);
-    vs.store(smem + 2 * KVB, tid);
+    ks.store(kimg, tid);
+    vs.store(vimg, tid);
     __syncthreads();
 
-    f32x16 oacc[2];
+    f32x16 oacc[DB];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { oacc[0][r] = 0.f; oacc[1][r] = 0.f; }
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
     float m = -INFINITY, l = 0.f;
     const float sl = scale * LOG2E_F;
     // running (key row, key col) of the four 4-key runs this lane owns in the current tile
@@ -68,16 +77,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
             ks.load(kbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
             vs.load(vbase + (size_t)(j + 1) * 32 * ldq, ldq, tid);
         }
-        const unsigned char* kt = smem + (j & 1) * KVB;
-        const unsigned char* vt = smem + (2 + (j & 1)) * KVB;
+        const unsigned char* kt = kimg + (j & 1) * KB;
+        const unsigned char* vt = vimg + (j & 1) * VB;
         if (valid) {
             f32x16 sacc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < KS; ++s) {
                 Frag<T> kf;
-                load_rowfrag<T>(kf, kt, lane & 31, s, g);
+                load_rowfrag<T, HD>(kf, kt, lane & 31, s, g);
                 mma(sacc, kf, qf[s]);
             }
             float p[16];
@@ -104,16 +113,18 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
             l = l * alpha + rs;
             m = mn;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { oacc[0][r] *= alpha; oacc[1][r] *= alpha; }
+            for (int db = 0; db < DB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
             Frag<T> pf[2];
             pack_frag<T>(pf[0], p);
             pack_frag<T>(pf[1], p + 8);
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
+            for (int db = 0; db < DB; ++db)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
                     Frag<T> vf;
-                    load_trfrag<T>(vf, vt, db * 32 + (lane & 31), s, g);
+                    load_trfrag<T, HD>(vf, vt, db * 32 + (lane & 31), s, g);
                     mma(oacc[db], vf, pf[s]);
                 }
 #pragma unroll
@@ -124,28 +135,30 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
             }
         }
         if (j + 1 < ntile) {
-            ks.store(smem + ((j + 1) & 1) * KVB, tid);
-            vs.store(smem + (2 + ((j + 1) & 1)) * KVB, tid);
+            ks.store(kimg + ((j + 1) & 1) * KB, tid);
+            vs.store(vimg + ((j + 1) & 1) * VB, tid);
         }
         __syncthreads();
     }
 
     // epilogue: normalise, stage O^T through this wave's (now free) table region, store whole rows
-    unsigned char* stg = smem + 4 * KVB + (size_t)wave * tab_stride;
-    constexpr int ROWB = ATT_HD * sizeof(T);
+    unsigned char* stg = wreg;
+    constexpr int ROWB = HD * sizeof(T);
     if (valid) {
         const float lt = l + lane_xor32(l);
         const float inv = 1.f / lt;
         if (g == 0) lse[(size_t)bh * L + q] = (m + __builtin_amdgcn_logf(lt)) * LN2_F;   // v_log_f32 = log2
 #pragma unroll
-        for (int db = 0; db < 2; ++db)
+        for (int db = 0; db < DB; ++db)
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int d0 = db * 32 + 8 * rg + 4 * g;
-                T* dst = reinterpret_cast<T*>(stg + (lane & 31) * ROWB) + d0;
-                const float a = oacc[db][rg * 4] * inv, bb = oacc[db][rg * 4 + 1] * inv, c = oacc[db][rg * 4 + 2] * inv,
-                            d = oacc[db][rg * 4 + 3] * inv;
-                *reinterpret_cast<typename TT<T>::Vec4*>(dst) = cvt4(a, bb, c, d, (T*)nullptr);
+                if (d0 < HD) {                                     // rows d >= HD of the last block are padding
+                    T* dst = reinterpret_cast<T*>(stg + (lane & 31) * ROWB) + d0;
+                    const float a = oacc[db][rg * 4] * inv, bb = oacc[db][rg * 4 + 1] * inv, c = oacc[db][rg * 4 + 2] * inv,
+                                d = oacc[db][rg * 4 + 3] * inv;
+                    *reinterpret_cast<typename TT<T>::Vec4*>(dst) = cvt4(a, bb, c, d, (T*)nullptr);
+                }
             }
     }
     __syncthreads();
@@ -155,44 +168,47 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const T* __restrict__
         for (int i = 0; i < 32 * CPR / 64; ++i) {
             const int c = lane + 64 * i, row = c / CPR, ch = c % CPR;
             const uint4 v = *reinterpret_cast<const uint4*>(stg + row * ROWB + ch * 16);
-            *reinterpret_cast<uint4*>(out + (size_t)(b * L + qt * 32 + row) * ldo + h * ATT_HD + ch * TT<T>::EPC) = v;
+            *reinterpret_cast<uint4*>(out + (size_t)(b * L + qt * 32 + row) * ldo + h * HD + ch * TT<T>::EPC) = v;
         }
     }
 }
 
 // Rcat[r][:] = rel_pos_h rows, then rel_pos_w rows, zero padded to NRP rows (T-typed operand for the bias MFMAs)
-template <typename T> __global__ void relpos_pack_kernel(const float* rh, int nh, const float* rw, int nw, T* out, int NRP) {
+template <typename T> __global__ void relpos_pack_kernel(const float* rh, int nh, const float* rw, int nw, T* out, int NRP, int hd) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= NRP * ATT_HD) return;
-    const int r = i / ATT_HD, d = i % ATT_HD;
+    if (i >= NRP * hd) return;
+    const int r = i / hd, d = i % hd;
     float v = 0.f;
-    if (r < nh) v = rh[r * ATT_HD + d];
-    else if (r - nh < nw) v = rw[(r - nh) * ATT_HD + d];
+    if (r < nh) v = rh[r * hd + d];
+    else if (r - nh < nw) v = rw[(r - nh) * hd + d];
     out[i] = from_f<T>(v);
 }
 extern "C" int pa_relpos_rows_padded(int Hp, int Wp) { return ((2 * Hp - 1 + 2 * Wp - 1) + 31) / 32 * 32; }
-extern "C" int pa_relpos_pack(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcat, int Hp, int Wp, hipStream_t st) {
+static bool head_dim_ok(int hd) { return hd == 64 || hd == 80; }       // instantiated head dims (attn_fwd_launch / attn_bwd_t)
+extern "C" int pa_relpos_pack(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcat, int Hp, int Wp, int head_dim,
+                              hipStream_t st) {
+    if (head_dim <= 0 || head_dim % 16) return (int)hipErrorInvalidValue;
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
-    const int n = NRP * ATT_HD;
+    const int n = NRP * head_dim;
     if (dtype == PA_BF16)
-        PA_LAUNCH(relpos_pack_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (bf16*)rcat, NRP);
+        PA_LAUNCH(relpos_pack_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (bf16*)rcat, NRP, head_dim);
     else
-        PA_LAUNCH(relpos_pack_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (float*)rcat, NRP);
+        PA_LAUNCH(relpos_pack_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, rel_pos_h, 2 * Hp - 1, rel_pos_w, 2 * Wp - 1, (float*)rcat, NRP, head_dim);
     LAUNCH_CHECK();
 }
 
-static int attn_tab_stride(int Hp, int Wp, int elem) {
-    int a = 32 * (Hp + Wp) * 4, b = 32 * ATT_HD * elem;
+static int attn_tab_stride(int Hp, int Wp, int hd, int elem) {
+    int a = 32 * (Hp + Wp) * 4, b = 32 * hd * elem;
     int s = a > b ? a : b;
     return (s + 15) / 16 * 16;
 }
-template <typename T, int NW>
+template <typename T, int NW, int HD>
 static int attn_fwd_launch(const T* qkv, int64_t ldq, const T* rcat, T* out, int64_t ldo, float* lse, int Bn, int L, int H, int Hp,
                            int Wp, float scale, hipStream_t st) {
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
-    const int ts = attn_tab_stride(Hp, Wp, sizeof(T));
-    const size_t smem = 4 * KvTile<T>::BYTES + (size_t)NW * ts;
-    auto kern = attn_fwd_kernel<T, NW>;
+    const int ts = attn_tab_stride(Hp, Wp, HD, sizeof(T));
+    const size_t smem = 2 * KvTile<T, HD>::KB + 2 * KvTile<T, HD>::VB + (size_t)NW * ts;
+    auto kern = attn_fwd_kernel<T, NW, HD>;
     static bool done = false;
     if (!done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -205,23 +221,27 @@ static int attn_fwd_launch(const T* qkv, int64_t ldq, const T* rcat, T* out, int
     PA_LAUNCH(kern, grid, dim3(NW * 64), smem, st, qkv, (size_t)ldq, rcat, out, (size_t)ldo, lse, L, H, Hp, Wp, NRP, scale, ts);
     return (int)hipGetLastError();
 }
+template <typename T>
+static int attn_fwd_t(const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse, int Bn, int L, int H, int Hp,
+                      int Wp, int hd, float scale, hipStream_t st) {
+    const T *q = (const T*)qkv, *r = (const T*)rcat;
+    T* o = (T*)out;
+    if (hd == 80) return attn_fwd_launch<T, 4, 80>(q, ldq, r, o, ldo, lse, Bn, L, H, Hp, Wp, scale, st);
+    if ((L / 32) % 7 == 0) return attn_fwd_launch<T, 7, 64>(q, ldq, r, o, ldo, lse, Bn, L, H, Hp, Wp, scale, st);
+    return attn_fwd_launch<T, 4, 64>(q, ldq, r, o, ldo, lse, Bn, L, H, Hp, Wp, scale, st);
+}
 
-// qkv: [B', L, 3, H, 64] T (row stride ldq = 3*H*64); rcat from pa_relpos_pack; out: [B'*L, H*64] T; lse: [B'*H, L] fp32
-extern "C" int64_t pa_attn_tables_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp) {
-    return dtype == PA_BF16 ? attn3_table_bytes(batch, L, heads, Hp, Wp) : 0;
+// qkv: [B', L, 3, H, hd] T (row stride ldq = 3*H*hd); rcat from pa_relpos_pack; out: [B'*L, H*hd] T; lse: [B'*H, L] fp32
+extern "C" int64_t pa_attn_tables_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp, int head_dim) {
+    return dtype == PA_BF16 && head_dim == ATT_HD ? attn3_table_bytes(batch, L, heads, Hp, Wp) : 0;
 }
 extern "C" int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse, void* tables,
-                           int batch, int L, int heads, int Hp, int Wp, float scale, hipStream_t st) {
-    if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4 || 32 % 4) return (int)hipErrorInvalidValue;
-    const bool seven = ((L / 32) % 7 == 0);
-    if (dtype == PA_BF16 && attn3_ok(L, Hp, Wp))
+                           int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t st) {
+    if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4 || !head_dim_ok(head_dim)) return (int)hipErrorInvalidValue;
+    if (dtype == PA_BF16 && head_dim == ATT_HD && attn3_ok(L, Hp, Wp))
         return attn3_fwd((const bf16*)qkv, ldq, (const bf16*)rcat, (bf16*)out, ldo, lse, tables, batch, L, heads, Hp, Wp, scale, st);
-    if (dtype == PA_BF16 && attn2_ok(L, Hp, Wp))
+    if (dtype == PA_BF16 && head_dim == ATT_HD && attn2_ok(L, Hp, Wp))
         return attn2_fwd((const bf16*)qkv, ldq, (const bf16*)rcat, (bf16*)out, ldo, lse, batch, L, heads, Hp, Wp, scale, st);
-    if (dtype == PA_BF16) {
-        if (seven) return attn_fwd_launch<bf16, 7>((const bf16*)qkv, ldq, (const bf16*)rcat, (bf16*)out, ldo, lse, batch, L, heads, Hp, Wp, scale, st);
-        return attn_fwd_launch<bf16, 4>((const bf16*)qkv, ldq, (const bf16*)rcat, (bf16*)out, ldo, lse, batch, L, heads, Hp, Wp, scale, st);
-    }
-    if (seven) return attn_fwd_launch<float, 7>((const float*)qkv, ldq, (const float*)rcat, (float*)out, ldo, lse, batch, L, heads, Hp, Wp, scale, st);
-    return attn_fwd_launch<float, 4>((const float*)qkv, ldq, (const float*)rcat, (float*)out, ldo, lse, batch, L, heads, Hp, Wp, scale, st);
+    if (dtype == PA_BF16) return attn_fwd_t<bf16>(qkv, ldq, rcat, out, ldo, lse, batch, L, heads, Hp, Wp, head_dim, scale, st);
+    return attn_fwd_t<float>(qkv, ldq, rcat, out, ldo, lse, batch, L, heads, Hp, Wp, head_dim, scale, st);
 }

@@ -10,10 +10,13 @@
 
 // ------------------------------------------------------------------------------- patch embed operands
 // A(row = token t in [0, S*B*L), k = c*P*P + ph*P + pw) = img_s[b, c, h*P+ph, w*P+pw]   (fp32 NCHW source)
-template <typename T> struct OpPatch {
+// GEN = false: P % 8 == 0, a 16-byte operand chunk is 8 (bf16) / 4 (fp32) consecutive pixels of one patch row, loaded as float4s.
+// GEN = true : any P (ViT-H/14: P = 14, K = 588): element-wise gather, k >= kreal (the zero padding of K up to a multiple of 8) reads 0.
+template <typename T, bool GEN = false> struct OpPatch {
     static constexpr bool TRANS = false;
     const float* img0; const float* img1;      // stream 0 (imgs), stream 1 (tgts)
     int Bn, Hp, Wp, P, rows;                   // rows = S*B*L
+    int kreal;                                 // 3*P*P
     struct Ctx { const float* base; };          // pixel (h*P, w*P) of channel 0, or nullptr
     DEVI void batch(int) {}
     DEVI Ctx ctx(int row) const {
@@ -23,8 +26,21 @@ template <typename T> struct OpPatch {
         const float* img = s ? img1 : img0;
         return Ctx{img + ((size_t)b * 3 * Hp * P + h * P) * (size_t)(Wp * P) + w * P};
     }
+    DEVI float elem(Ctx c, int k) const {
+        if (k >= kreal) return 0.f;
+        const int PP = P * P, ch = k / PP, ph = (k % PP) / P, pw = k % P;
+        return c.base[((size_t)ch * Hp * P + ph) * (size_t)(Wp * P) + pw];
+    }
     DEVI uint4 chunk(Ctx c, int k, int kend) const {
         if (c.base == nullptr || k >= kend) return zero4();
+        if constexpr (GEN) {
+            if constexpr (sizeof(T) == 2)
+                return make_uint4(pack_bf16x2(elem(c, k), elem(c, k + 1)), pack_bf16x2(elem(c, k + 2), elem(c, k + 3)),
+                                  pack_bf16x2(elem(c, k + 4), elem(c, k + 5)), pack_bf16x2(elem(c, k + 6), elem(c, k + 7)));
+            else
+                return make_uint4(__builtin_bit_cast(uint32_t, elem(c, k)), __builtin_bit_cast(uint32_t, elem(c, k + 1)),
+                                  __builtin_bit_cast(uint32_t, elem(c, k + 2)), __builtin_bit_cast(uint32_t, elem(c, k + 3)));
+        }
         const int PP = P * P, ch = k / PP, ph = (k % PP) / P, pw = k % P;
         const float* src = c.base + ((size_t)ch * Hp * P + ph) * (size_t)(Wp * P) + pw;
         if constexpr (sizeof(T) == 2) {
@@ -36,7 +52,7 @@ template <typename T> struct OpPatch {
     }
 };
 // contraction-major view of the same matrix for the weight gradient: vec(kk = token, r = k index)
-template <typename T> struct OpPatchT {
+template <typename T, bool GEN = false> struct OpPatchT {
     static constexpr bool TRANS = true;
     typedef typename TT<T>::Vec4 Vec4;
     typedef int Ctx;
@@ -50,6 +66,16 @@ template <typename T> struct OpPatchT {
         const int s = kk / BL, rr = kk % BL, b = rr / L, l = rr % L, h = l / Wp, w = l % Wp;
         const int PP = P * P, ch = r / PP, ph = (r % PP) / P, pw = r % P;
         const float* img = s ? img1 : img0;
+        if constexpr (GEN) {                     // 4 consecutive k indices may wrap to the next patch row / channel; r + e >= rows reads 0
+            float e4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int re = r + e;
+                const int che = re / PP, phe = (re % PP) / P, pwe = re % P;
+                e4[e] = re < rows ? img[(((size_t)b * 3 + che) * Hp * P + h * P + phe) * (size_t)(Wp * P) + w * P + pwe] : 0.f;
+            }
+            return cvt4(e4[0], e4[1], e4[2], e4[3], (T*)nullptr);
+        }
         const float4 a = *reinterpret_cast<const float4*>(img + (((size_t)b * 3 + ch) * Hp * P + h * P + ph) * (size_t)(Wp * P) + w * P + pw);
         return cvt4(a.x, a.y, a.z, a.w, (T*)nullptr);
     }
@@ -86,22 +112,38 @@ struct EpiPatchTokens {
 };
 
 template <typename T>
-static int patch_fwd_t(const float* imgs, const float* tgts, const T* w, EpiPatchTokens ep, int Bn, int Hp, int Wp, int P, int D, hipStream_t st) {
-    const int M = 2 * Bn * Hp * Wp, K = 3 * P * P;
-    OpPatch<T> A{imgs, tgts, Bn, Hp, Wp, P, M};
-    OpN<T> B{w, (size_t)K, D, 0};
-    return launch_gemm<T, 2, 2>(A, B, ep, M, D, K, 1, 1, st);
+static int patch_fwd_t(const float* imgs, const float* tgts, const T* w, int64_t ldw, EpiPatchTokens ep, int Bn, int Hp, int Wp, int P, int D,
+                       hipStream_t st) {
+    const int M = 2 * Bn * Hp * Wp, K = 3 * P * P, Kp = (K + 7) / 8 * 8;
+    OpN<T> B{w, (size_t)ldw, D, 0};
+    if (P % 8 == 0) return launch_gemm<T, 2, 2>(OpPatch<T, false>{imgs, tgts, Bn, Hp, Wp, P, M, K}, B, ep, M, D, K, 1, 1, st);
+    return launch_gemm<T, 2, 2>(OpPatch<T, true>{imgs, tgts, Bn, Hp, Wp, P, M, K}, B, ep, M, D, Kp, 1, 1, st);
 }
-extern "C" int pa_patch_embed_fwd(int dtype, const float* imgs, const float* tgts, const void* w, const float* bias,
+// w [D, 3*P*P] f32 (the conv weight, flattened) -> T [D, Kp], Kp = 3*P*P rounded up to 8, zero padded: the layout pa_patch_embed_fwd
+// takes with ldw = Kp (for P % 8 == 0 that is a plain cast)
+template <typename T> __global__ void patch_weight_pack_kernel(const float* __restrict__ w, T* __restrict__ out, int D, int K, int Kp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D * Kp) return;
+    const int d = i / Kp, k = i - d * Kp;
+    out[i] = from_f<T>(k < K ? w[(size_t)d * K + k] : 0.f);
+}
+extern "C" int pa_patch_weight_pack(int dtype, const float* w, void* out, int D, int P, hipStream_t st) {
+    const int K = 3 * P * P, Kp = (K + 7) / 8 * 8, n = D * Kp;
+    if (dtype == PA_BF16) PA_LAUNCH(patch_weight_pack_kernel<bf16>, dim3((n + 255) / 256), dim3(256), 0, st, w, (bf16*)out, D, K, Kp);
+    else PA_LAUNCH(patch_weight_pack_kernel<float>, dim3((n + 255) / 256), dim3(256), 0, st, w, (float*)out, D, K, Kp);
+    LAUNCH_CHECK();
+}
+extern "C" int pa_patch_embed_fwd(int dtype, const float* imgs, const float* tgts, const void* w, int64_t ldw, const float* bias,
                                   const float* mask_token, const float* seg_x, const float* seg_y, const float* pos,
                                   const unsigned char* mask, int mask_batch_stride, const float* type_cls,
                                   const float* type_ins, const float* seg_type, float* tokens, int batch, int Hp, int Wp, int P,
                                   int D, hipStream_t st) {
-    if (P % 8) return (int)hipErrorInvalidValue;
+    const int Kp = (3 * P * P + 7) / 8 * 8;
+    if (P < 1 || ldw < Kp || ldw % 8) return (int)hipErrorInvalidValue;
     EpiPatchTokens ep{tokens, (size_t)D, bias, mask_token, seg_x, seg_y, pos, mask, mask_batch_stride, type_cls, type_ins, seg_type,
                       batch, Hp * Wp, 2 * batch * Hp * Wp, D};
-    if (dtype == PA_BF16) return patch_fwd_t<bf16>(imgs, tgts, (const bf16*)w, ep, batch, Hp, Wp, P, D, st);
-    return patch_fwd_t<float>(imgs, tgts, (const float*)w, ep, batch, Hp, Wp, P, D, st);
+    if (dtype == PA_BF16) return patch_fwd_t<bf16>(imgs, tgts, (const bf16*)w, ldw, ep, batch, Hp, Wp, P, D, st);
+    return patch_fwd_t<float>(imgs, tgts, (const float*)w, ldw, ep, batch, Hp, Wp, P, D, st);
 }
 
 struct EpiSlabC {
@@ -121,15 +163,16 @@ template <typename T>
 static int patch_wgrad_t(const T* dpe, const float* imgs, const float* tgts, float* dw, float* ws, int Bn, int Hp, int Wp, int P, int D, hipStream_t st) {
     const int R = 2 * Bn * Hp * Wp, K = 3 * P * P;
     OpT<T> A{dpe, (size_t)D, D, 0};
-    OpPatchT<T> B{imgs, tgts, Bn, Hp, Wp, P, K};
-    int e = launch_gemm<T, 2, 2>(A, B, EpiSlabC{ws, (size_t)K, (size_t)D * K, D, K}, D, K, R, PATCH_WGRAD_SPLITS, 1, st);
+    int e;
+    if (P % 4 == 0) e = launch_gemm<T, 2, 2>(A, OpPatchT<T, false>{imgs, tgts, Bn, Hp, Wp, P, K}, EpiSlabC{ws, (size_t)K, (size_t)D * K, D, K}, D, K, R, PATCH_WGRAD_SPLITS, 1, st);
+    else e = launch_gemm<T, 2, 2>(A, OpPatchT<T, true>{imgs, tgts, Bn, Hp, Wp, P, K}, EpiSlabC{ws, (size_t)K, (size_t)D * K, D, K}, D, K, R, PATCH_WGRAD_SPLITS, 1, st);
     if (e) return e;
     return pa_slab_reduce(ws, dw, (int64_t)D * K, PATCH_WGRAD_SPLITS, (int64_t)D * K, 0, st);
 }
 // dW[D, 3*P*P] = dPE[2BL, D]^T . im2col(imgs;tgts)
 extern "C" int pa_patch_embed_wgrad(int dtype, const void* dpe, const float* imgs, const float* tgts, float* dw, void* workspace,
                                     int batch, int Hp, int Wp, int P, int D, hipStream_t st) {
-    if (P % 4) return (int)hipErrorInvalidValue;
+    if (P < 1 || D % 4) return (int)hipErrorInvalidValue;
     if (dtype == PA_BF16) return patch_wgrad_t<bf16>((const bf16*)dpe, imgs, tgts, dw, (float*)workspace, batch, Hp, Wp, P, D, st);
     return patch_wgrad_t<float>((const float*)dpe, imgs, tgts, dw, (float*)workspace, batch, Hp, Wp, P, D, st);
 }

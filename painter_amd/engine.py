@@ -73,10 +73,11 @@ class HotPathConfig:
         """The HIP path's structural requirements (fail loudly, there is no fallback)."""
         hd = self.D // self.heads
         err = []
-        if hd != 64: err.append("head_dim must be 64 (got %d)" % hd)
+        if hd not in (64, 80) or hd * self.heads != self.D:
+            err.append("head_dim must be 64 (the reference factories) or 80 (ViT-H/14, BASELINE configs[4]); got %d" % hd)
         if self.dec != 64: err.append("decoder_embed_dim must be 64 (got %d)" % self.dec)
         if self.L % 32 or self.Hp % 4 or self.Wp % 4: err.append("token grid %dx%d must have Hp,Wp %% 4 == 0 and L %% 32 == 0" % (self.Hp, self.Wp))
-        if self.P % 8: err.append("patch_size must be a multiple of 8")
+        if self.H % self.P or self.W % self.P or (self.W * self.P) % 4: err.append("image %dx%d is not a whole number of %d-pixel patches" % (self.H, self.W, self.P))
         if self.D % 8 or self.hidden % 8: err.append("embed/hidden dims must be multiples of 8")
         if not self.use_rel_pos: err.append("use_rel_pos=False is not built (the reference factories always enable it)")
         if self.H != 2 * self.W: err.append("img_size must be (2W, W) (patchify asserts H == 2W, models_painter.py:361)")
@@ -101,6 +102,8 @@ class HotPath:
         self.T = compute_dtype
         self._M = None
         self._wcache = {}
+        self._pcache = {}
+        self._rcache = {}
         self._side = {}
         # parameter-gradient kernels (dW = dY^T.X, bias column sums) are off the backward's critical path: they go to a second HIP
         # stream (+3.5 % at B=8; PAINTER_AMD_SIDE_STREAM=0 turns it off).  This mode exposed two things, both fixed: a cross-stream
@@ -137,6 +140,35 @@ class HotPath:
             return buf
         return ent[1]
 
+    def w_patch(self, P):
+        """The patch-embed conv weight as the T [D, Kp] operand pa_patch_embed_fwd takes (Kp = 3*P*P rounded up to 8, zero padded).
+        For P % 8 == 0 that is the ordinary T copy; otherwise (P = 14) a packed copy, cached on the parameter version like w()."""
+        c = self.cfg
+        if c.P % 8 == 0:
+            return self.w("patch_embed.proj.weight", P)
+        t = P["patch_embed.proj.weight"]
+        key = ("patch_embed.proj.weight#packed", t.data_ptr())
+        ent = self._pcache.get(key)
+        if ent is None or ent[0] != t._version or ent[1].device != t.device:
+            buf = ops.patch_weight_pack(t, self.T, c.P, out=ent[1] if ent is not None and ent[1].device == t.device else None)
+            self._pcache = {key: (t._version, buf)}
+            return buf
+        return ent[1]
+
+    def relpos(self, pre, P, transposed):
+        """Rcat / Rcat^T operands of block `pre`, packed once per parameter version (they used to be re-packed in every forward and
+        every backward of every block: 48 tiny launches per step)."""
+        c = self.cfg
+        rh, rw = P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"]
+        key = (pre, transposed, rh.data_ptr(), rw.data_ptr())
+        ent = self._rcache.get(key)
+        ver = (rh._version, rw._version)
+        if ent is None or ent[0] != ver or ent[1].device != rh.device:
+            buf = (ops.relpos_pack_t if transposed else ops.relpos_pack)(rh, rw, c.Hp, c.Wp, self.T)
+            self._rcache[key] = (ver, buf)
+            return buf
+        return ent[1]
+
     def shadow_buffers(self):
         """{parameter data_ptr: cached bf16 copy} -- lets painter_amd.optim.AdamW refresh the copies inside its update pass."""
         return {key[1]: ent[1] for key, ent in self._wcache.items()}
@@ -162,7 +194,7 @@ class HotPath:
         M = self.pos_operator(dev)
         pe = P["pos_embed"][0, c.cls:]
         pos = ops.pos_fwd(M, pe, L, c.src * c.src, D)
-        x = ops.patch_embed_fwd(T, imgs, tgts, self.w("patch_embed.proj.weight", P), P["patch_embed.proj.bias"],
+        x = ops.patch_embed_fwd(T, imgs, tgts, self.w_patch(P), P["patch_embed.proj.bias"],
                                 P["mask_token"], P["segment_token_x"], P["segment_token_y"], pos, mask_u8,
                                 P.get("type_token_cls") if c.seggpt else None, P.get("type_token_ins") if c.seggpt else None,
                                 seg_type if c.seggpt else None, B, c.Hp, c.Wp, c.P, D)
@@ -178,7 +210,7 @@ class HotPath:
             ds_a, ds_m = (None, None) if drop_scales is None else drop_scales[i]
             ln1, mean1, rstd1 = ops.layernorm_fwd(x, P[pre + "norm1.weight"], P[pre + "norm1.bias"], c.ln_eps, T)
             qkv = ops.linear_fwd(ln1, self.w(pre + "attn.qkv.weight", P), P[pre + "attn.qkv.bias"], EPI_BIAS)
-            rcat = ops.relpos_pack(P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], c.Hp, c.Wp, T)
+            rcat = self.relpos(pre, P, False)
             ao, lse, atab = ops.attn_fwd(qkv, rcat, Bc, L, c.heads, c.Hp, c.Wp, c.scale, need_tables=True) if need_grad else \
                 ops.attn_fwd(qkv, rcat, Bc, L, c.heads, c.Hp, c.Wp, c.scale) + (None,)
             if merge > 0:
@@ -350,7 +382,7 @@ class HotPath:
             dao = ops.linear_dgrad(dyA, self.w(pre + "attn.proj.weight", P), out=dln2)
             tr("%d.dao" % i, dao)
             del dyA
-            rcatT = ops.relpos_pack_t(P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"], c.Hp, c.Wp, T)
+            rcatT = self.relpos(pre, P, True)
             dqkv, dG = ops.attn_bwd_core(qkv, rcat, rcatT, ao, dao, lse, Bc, L, c.heads, c.Hp, c.Wp, c.scale, tables=atab)
             drcat = on_side(lambda: ops.attn_bwd_relpos(dG, qkv, rcat.shape[0], Bc, L, c.heads, c.Hp, c.Wp), dG, qkv)
             del dG

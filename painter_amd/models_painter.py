@@ -321,6 +321,19 @@ def painter_vit_large_patch16_input896x448_win_dec64_8glb_sl1(**kwargs):
     return model
 
 
+def painter_vit_huge_patch14_input896x448(**kwargs):
+    """BASELINE.json configs[4] (SURVEY.md 8d config 5).  NOT a reference factory: the reference only ships the ViT-L factory above;
+    this is its class constructor (models_painter.py:241-266) called with ViT-H/14 sizes -- patch 14, embed 1280, depth 32, 16 heads
+    (head_dim 80), 64 x 32 tokens, decoder_embed 5120 -> 14*14*64 -- with the feature taps generalised to depth/4*k - 1 = 7, 15, 23,
+    31 (the reference's hard-coded [5, 11, 17, 23], models_painter.py:416, would leave blocks 24-31 without gradient)."""
+    return Painter(
+        img_size=(896, 448), patch_size=14, embed_dim=1280, depth=32, num_heads=16,
+        drop_path_rate=0.1, window_size=14, qkv_bias=True,
+        mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+        window_block_indexes=(), residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat",
+        decoder_embed_dim=64, loss_func="smoothl1", **kwargs)
+
+
 # names used by BASELINE.json
 PainterViT = Painter
 painter_vit_large_patch16_input896x448 = painter_vit_large_patch16_input896x448_win_dec64_8glb_sl1

@@ -141,64 +141,72 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, dx=None, dxT=None, rowsca
 
 # ------------------------------------------------------------------------------------------- attention
 def relpos_pack(rel_pos_h, rel_pos_w, Hp, Wp, dtype):
+    """-> Rcat T [NRP, hd] = [rel_pos_h ; rel_pos_w ; 0] (hd = rel_pos_h.shape[1], the head dim)."""
     nrp = lib.pa_relpos_rows_padded(Hp, Wp)
-    rcat = torch.empty((nrp, 64), dtype=dtype, device=rel_pos_h.device)
-    check(lib.pa_relpos_pack(code(dtype), p(rel_pos_h), p(rel_pos_w), p(rcat), Hp, Wp, stream()), "pa_relpos_pack")
+    hd = rel_pos_h.shape[1]
+    assert rel_pos_h.shape == (2 * Hp - 1, hd) and rel_pos_w.shape == (2 * Wp - 1, hd)
+    rcat = torch.empty((nrp, hd), dtype=dtype, device=rel_pos_h.device)
+    check(lib.pa_relpos_pack(code(dtype), p(rel_pos_h), p(rel_pos_w), p(rcat), Hp, Wp, hd, stream()), "pa_relpos_pack")
     return rcat
 
 
 def attn_fwd(qkv, rcat, batch, L, heads, Hp, Wp, scale, need_tables=False):
-    """qkv [batch*L, 3*heads*64] T -> (out [batch*L, heads*64] T, lse [batch*heads, L] f32[, tables]).
+    """qkv [batch*L, 3*heads*hd] T -> (out [batch*L, heads*hd] T, lse [batch*heads, L] f32[, tables]).
     need_tables: also return the per-query bias tables the backward reuses (None when the kernels in use do not export them)."""
     T = qkv.dtype
-    out = torch.empty((batch * L, heads * 64), dtype=T, device=qkv.device)
+    hd = rcat.shape[1]
+    assert qkv.shape[1] == 3 * heads * hd
+    out = torch.empty((batch * L, heads * hd), dtype=T, device=qkv.device)
     lse = torch.empty((batch * heads, L), dtype=torch.float32, device=qkv.device)
     tables = None
     if need_tables:
-        nb = lib.pa_attn_tables_bytes(code(T), batch, L, heads, Hp, Wp)
+        nb = lib.pa_attn_tables_bytes(code(T), batch, L, heads, Hp, Wp, hd)
         if nb > 0:
             tables = torch.empty((nb,), dtype=torch.uint8, device=qkv.device)
     check(lib.pa_attn_fwd(code(T), p(qkv), qkv.stride(0), p(rcat), p(out), out.stride(0), p(lse), p(tables), batch, L, heads,
-                          Hp, Wp, float(scale), stream()), "pa_attn_fwd")
+                          Hp, Wp, hd, float(scale), stream()), "pa_attn_fwd")
     return (out, lse, tables) if need_tables else (out, lse)
 
 
 def relpos_pack_t(rel_pos_h, rel_pos_w, Hp, Wp, dtype):
     nrp = lib.pa_relpos_rows_padded(Hp, Wp)
-    rcatT = torch.empty((64, nrp), dtype=dtype, device=rel_pos_h.device)
-    check(lib.pa_relpos_pack_t(code(dtype), p(rel_pos_h), p(rel_pos_w), p(rcatT), Hp, Wp, stream()), "pa_relpos_pack_t")
+    hd = rel_pos_h.shape[1]
+    rcatT = torch.empty((hd, nrp), dtype=dtype, device=rel_pos_h.device)
+    check(lib.pa_relpos_pack_t(code(dtype), p(rel_pos_h), p(rel_pos_w), p(rcatT), Hp, Wp, hd, stream()), "pa_relpos_pack_t")
     return rcatT
 
 
 def attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale, tables=None):
-    """-> (dqkv T [batch*L, 3*heads*64], dG T [batch*L, heads*NRP]): the data gradients and the per-query bias gradients.
+    """-> (dqkv T [batch*L, 3*heads*hd], dG T [batch*L, heads*NRP]): the data gradients and the per-query bias gradients.
     tables: what attn_fwd(need_tables=True) returned (the backward writes its lse / delta fields into it)."""
     T = qkv.dtype
     dev = qkv.device
-    nrp = rcat.shape[0]
+    nrp, hd = rcat.shape
     delta = torch.empty((batch * heads, L), dtype=torch.float32, device=dev)
-    check(lib.pa_attn_bwd_delta(code(T), p(out), out.stride(0), p(dout), dout.stride(0), p(delta), batch, L, heads,
+    check(lib.pa_attn_bwd_delta(code(T), p(out), out.stride(0), p(dout), dout.stride(0), p(delta), batch, L, heads, hd,
                                 stream()), "pa_attn_bwd_delta")
     dqkv = torch.empty_like(qkv)
     dG = torch.empty((batch * L, heads * nrp), dtype=T, device=dev)
     aux = workspace(lib.pa_attn_bwd_aux_bytes(batch, L, heads, Hp, Wp), dev, slot=1)
     check(lib.pa_attn_bwd(code(T), p(qkv), qkv.stride(0), p(rcat), p(rcatT), p(dout), dout.stride(0), p(lse), p(delta),
-                          p(dqkv), p(dG), p(aux), p(tables), batch, L, heads, Hp, Wp, float(scale), stream()), "pa_attn_bwd")
+                          p(dqkv), p(dG), p(aux), p(tables), batch, L, heads, Hp, Wp, hd, float(scale), stream()), "pa_attn_bwd")
     return dqkv, dG
 
 
-def attn_bwd_relpos(dG, qkv, nrp, batch, L, heads, Hp, Wp):
-    """-> drcat f32 [NRP, 64] = d[rel_pos_h ; rel_pos_w ; pad]: a parameter gradient (nothing downstream consumes it)."""
+def attn_bwd_relpos(dG, qkv, nrp, batch, L, heads, Hp, Wp, out=None):
+    """-> drcat f32 [NRP, hd] = d[rel_pos_h ; rel_pos_w ; pad]: a parameter gradient (nothing downstream consumes it)."""
     T = qkv.dtype
-    drcat = torch.empty((nrp, 64), dtype=torch.float32, device=qkv.device)
-    ws = workspace(lib.pa_attn_bwd_relpos_workspace_bytes(code(T), batch, L, heads, Hp, Wp), qkv.device)
-    check(lib.pa_attn_bwd_relpos(code(T), p(dG), p(qkv), qkv.stride(0), p(drcat), p(ws), batch, L, heads, Hp, Wp,
+    hd = qkv.shape[1] // (3 * heads)
+    drcat = out if out is not None else torch.empty((nrp, hd), dtype=torch.float32, device=qkv.device)
+    assert drcat.shape == (nrp, hd) and drcat.is_contiguous()
+    ws = workspace(lib.pa_attn_bwd_relpos_workspace_bytes(code(T), batch, L, heads, Hp, Wp, hd), qkv.device)
+    check(lib.pa_attn_bwd_relpos(code(T), p(dG), p(qkv), qkv.stride(0), p(drcat), p(ws), batch, L, heads, Hp, Wp, hd,
                                  stream()), "pa_attn_bwd_relpos")
     return drcat
 
 
 def attn_bwd(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale, tables=None):
-    """-> (dqkv T [batch*L, 3*heads*64], drcat f32 [NRP, 64])."""
+    """-> (dqkv T [batch*L, 3*heads*hd], drcat f32 [NRP, hd])."""
     dqkv, dG = attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale, tables=tables)
     return dqkv, attn_bwd_relpos(dG, qkv, rcat.shape[0], batch, L, heads, Hp, Wp)
 
@@ -221,11 +229,23 @@ def pos_bwd(M, gx, gy, dpe, L, S, D):
     check(lib.pa_pos_bwd(p(M), p(gx), p(gy), p(dpe), L, S, D, stream()), "pa_pos_bwd")
 
 
+def patch_weight_pack(w, T, P, out=None):
+    """conv weight f32 [D, 3, P, P] -> T [D, Kp] (Kp = 3*P*P rounded up to 8, zero padded): the operand pa_patch_embed_fwd takes."""
+    D = w.shape[0]
+    kp = (3 * P * P + 7) // 8 * 8
+    if out is None:
+        out = torch.empty((D, kp), dtype=T, device=w.device)
+    check(lib.pa_patch_weight_pack(code(T), p(w), p(out), D, P, stream()), "pa_patch_weight_pack")
+    return out
+
+
 def patch_embed_fwd(T, imgs, tgts, w, bias, mask_token, seg_x, seg_y, pos, mask_u8, type_cls, type_ins, seg_type,
                     batch, Hp, Wp, P, D):
+    """w: T [D, ldw] as patch_weight_pack returns it (a plain [D, 3*P*P] T copy is the same thing when P % 8 == 0)."""
     tokens = torch.empty((2 * batch * Hp * Wp, D), dtype=torch.float32, device=imgs.device)
     mbs = 0 if mask_u8.shape[0] == 1 else mask_u8.stride(0)
-    check(lib.pa_patch_embed_fwd(code(T), p(imgs), p(tgts), p(w), p(bias), p(mask_token), p(seg_x), p(seg_y), p(pos),
+    assert w.dtype == T and w.shape[0] == D and w.stride(1) == 1
+    check(lib.pa_patch_embed_fwd(code(T), p(imgs), p(tgts), p(w), w.stride(0), p(bias), p(mask_token), p(seg_x), p(seg_y), p(pos),
                                  p(mask_u8), mbs, p(type_cls), p(type_ins), p(seg_type), p(tokens), batch, Hp, Wp, P, D,
                                  stream()), "pa_patch_embed_fwd")
     return tokens

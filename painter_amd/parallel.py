@@ -99,7 +99,8 @@ def broadcast_parameters(module, src=0, process_group=None):
             t.copy_(buf)
     hot = getattr(module, "_hot", None)
     if hot is not None:
-        hot._wcache.clear()                        # belt and braces: the shadow copies are rebuilt on the next forward
+        for cache in (hot._wcache, hot._pcache, hot._rcache):
+            cache.clear()                          # belt and braces: the T-typed operand copies are rebuilt on the next forward
 
 
 def _ipc_env():

@@ -11,8 +11,8 @@ recipe is part of the golden contract, so fixtures store only seeds + outputs, n
 
 Outputs (tests/golden/*.npz, float32):
   loss, pred (patchified) -- full tensors for tiny cases, a strided sample + moments for ViT-L
-  per-parameter gradient digests: L2 norm, sum, and dot with a seeded probe vector
-  (+ full gradients of parameters with <= 4096 elements).
+  per-parameter gradient digests: L2 norm, sum, and dot with a seeded probe vector; full gradients of parameters with
+  <= 4096 elements; every 997th element of every larger gradient (grad_sample/<name>).
 """
 import argparse
 import os
@@ -34,6 +34,7 @@ WINDOW_BLOCK_INDEXES = (list(range(0, 2)) + list(range(3, 5)) + list(range(6, 8)
                         list(range(12, 14)), list(range(15, 17)), list(range(18, 20)), list(range(21, 23)))
 PRED_STRIDE = 37          # ViT-L pred sample stride (flattened patchified pred)
 SMALL_PARAM = 4096
+GRAD_STRIDE = 997         # every 997th element (a prime: no aliasing with any row width) of every gradient with > SMALL_PARAM elements
 
 
 def build_reference(cfg: O.OracleConfig, seed: int):
@@ -77,10 +78,15 @@ def grad_digest(named_grads, out: dict, prefix: str):
         dots.append(float((g.double() * probe_vector(name, g.numel()).double()).sum()))
         if g.numel() <= SMALL_PARAM:
             out[f"{prefix}grad/{name}"] = g.numpy()
+        else:
+            # a strided sample of the tensor itself: unlike the norm / probe-dot digests (a random direction of the right norm
+            # changes the probe dot by only ~1.4/sqrt(n) of the scale) this can tell a wrong gradient from a right one
+            out[f"{prefix}grad_sample/{name}"] = g[::GRAD_STRIDE].clone().numpy()
     out[prefix + "grad_names"] = np.array(names)
     out[prefix + "grad_norm"] = np.array(norms, dtype=np.float64)
     out[prefix + "grad_sum"] = np.array(sums, dtype=np.float64)
     out[prefix + "grad_dot"] = np.array(dots, dtype=np.float64)
+    out[prefix + "grad_sample_stride"] = np.int64(GRAD_STRIDE)
 
 
 def case_painter(cfg, out, prefix, batch, mask_kind, seed_p=1, seed_x=1234, backward=True, train_mode=False):
@@ -249,6 +255,16 @@ def case_seggpt_vit_large_n32(out, prefix, n_prompts=32):
     out[prefix + "pred_norm"] = flat.double().norm(dim=1).numpy()
 
 
+def case_h14(out):
+    """hd = 80 / patch 14 arithmetic pinned to the UNMODIFIED reference: Painter(img_size=(112, 56), patch_size=14, embed_dim=160,
+    depth=24, num_heads=2) -- head_dim 80, an 8 x 4 token grid, the 16 x 16 pre-training position grid of patch 14 -- at depth 24, where
+    the reference's hard-coded taps [5, 11, 17, 23] (models_painter.py:416) ARE the generalised depth/4*k - 1.  (ViT-H/14 proper, depth
+    32, has no reference golden: its taps are an extension, SURVEY.md 8d note H.)"""
+    cfg = O.h14_small_config(depth=24)
+    case_painter(cfg, out, "h14_rand/", batch=2, mask_kind="random", seed_p=31, seed_x=41)
+    case_painter(cfg, out, "h14_train/", batch=2, mask_kind="half", seed_p=32, seed_x=42, train_mode=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also generate the ViT-L 896x448 fixture")
@@ -256,6 +272,8 @@ def main():
     ap.add_argument("--skip-tiny", action="store_true")
     ap.add_argument("--vitl-b8", action="store_true", help="only: ViT-L B=8 train-mode fixture (8 B=1 runs of the reference, ~3 min, 15 GB)")
     ap.add_argument("--seggpt-n32", action="store_true", help="only: SegGPT ViT-L N=32 feature-ensemble forward (~6 min)")
+    ap.add_argument("--h14", action="store_true", help="only: the head_dim 80 / patch 14 small fixture (seconds)")
+    ap.add_argument("--vitl-b1", action="store_true", help="only: ViT-L B=1 eval fixture (~2 min)")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
     if args.vitl_b8:
@@ -264,6 +282,15 @@ def main():
         np.savez_compressed(os.path.join(HERE, "painter_vitl_b8.npz"), **out)
         print("painter_vitl_b8.npz loss", out["vitl_b8_train/loss"])
         return
+    if args.h14:
+        out = {}
+        case_h14(out)
+        np.savez_compressed(os.path.join(HERE, "painter_h14.npz"), **out)
+        print("painter_h14.npz", {k: v for k, v in out.items() if k.endswith("loss")})
+        return
+    if args.vitl_b1:
+        args.full = True
+        return _rest(args, only_vitl=True)
     if args.seggpt_n32:
         out = {}
         case_seggpt_vit_large_n32(out, "seggpt_n32/")
@@ -292,8 +319,8 @@ def main():
     _rest(args)
 
 
-def _rest(args):
-    if args.small or args.full:
+def _rest(args, only_vitl=False):
+    if (args.small or args.full) and not only_vitl:
         out = {}
         small = O.small_config()
         case_painter(small, out, "painter_rand/", batch=2, mask_kind="random", seed_p=11, seed_x=21)

@@ -196,20 +196,21 @@ def test_layernorm_fwd_bwd(T, R, D):
 
 
 def attn_reference(qkv, rel_h, rel_w, B, L, H, Hp, Wp, scale):
-    """Painter/models_painter.py:76-86 + util/vitdet_utils.py:96-125 in fp64."""
-    D = H * 64
-    q, k, v = qkv.double().reshape(B, L, 3, H, 64).permute(2, 0, 3, 1, 4).reshape(3, B * H, L, 64).unbind(0)
+    """Painter/models_painter.py:76-86 + util/vitdet_utils.py:96-125 in fp64 (head dim from the operand shapes)."""
+    hd = rel_h.shape[1]
+    D = H * hd
+    q, k, v = qkv.double().reshape(B, L, 3, H, hd).permute(2, 0, 3, 1, 4).reshape(3, B * H, L, hd).unbind(0)
     attn = (q * scale) @ k.transpose(-2, -1)
     ih = (torch.arange(Hp)[:, None] - torch.arange(Hp)[None, :] + Hp - 1).to(qkv.device)
     iw = (torch.arange(Wp)[:, None] - torch.arange(Wp)[None, :] + Wp - 1).to(qkv.device)
     Rh, Rw = rel_h.double()[ih], rel_w.double()[iw]
-    rq = q.reshape(B * H, Hp, Wp, 64)
+    rq = q.reshape(B * H, Hp, Wp, hd)
     bh = torch.einsum("bhwc,hkc->bhwk", rq, Rh)
     bw = torch.einsum("bhwc,wkc->bhwk", rq, Rw)
     attn = (attn.view(B * H, Hp, Wp, Hp, Wp) + bh[..., :, None] + bw[..., None, :]).view(B * H, L, L)
     lse = torch.logsumexp(attn, dim=-1)
     o = attn.softmax(-1) @ v
-    return o.view(B, H, L, 64).permute(0, 2, 1, 3).reshape(B * L, D), lse
+    return o.view(B, H, L, hd).permute(0, 2, 1, 3).reshape(B * L, D), lse
 
 
 @pytest.fixture
@@ -276,6 +277,46 @@ def test_attn_bwd(T, B, H, Hp, Wp, gen_, attn_generation):
                 drw=relerr(drcat[nh:nh + nw], rw64.grad))
     assert max(errs.values()) < tol, errs
     assert float(drcat[nh + nw:].abs().max()) == 0.0 if drcat.shape[0] > nh + nw else True
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,Hp,Wp", [(2, 2, 8, 4), (1, 3, 16, 8), (1, 2, 64, 32), (2, 1, 8, 12)])
+def test_attn_head_dim_80_fwd_bwd(T, B, H, Hp, Wp):
+    """head_dim 80 (ViT-H/14, BASELINE configs[4]: 1280 / 16 heads; its token grid is 64 x 32): the generic kernels of attn_fwd.hip /
+    attn_bwd.hip instantiated for HD = 80 -- five 16-deep k-steps in Q.K^T / dO.V^T, three 32-row output blocks of which the last is
+    half padding -- forward (out, lse) and backward (dq, dk, dv, d rel_pos_h, d rel_pos_w) against the fp64 reference of
+    models_painter.py:76-86 + vitdet_utils.py:96-125.  Gates as for head_dim 64."""
+    hd = 80
+    L = Hp * Wp
+    nh, nw = 2 * Hp - 1, 2 * Wp - 1
+    scale = hd ** -0.5
+    qkv = gen((B * L, 3 * H * hd), 1, 1.0, T)
+    rel_h, rel_w = gen((nh, hd), 2, 0.2), gen((nw, hd), 3, 0.2)
+    dout = gen((B * L, H * hd), 4, 1.0, T)
+    rcat = ops.relpos_pack(rel_h, rel_w, Hp, Wp, T)
+    rcatT = ops.relpos_pack_t(rel_h, rel_w, Hp, Wp, T)
+    assert rcat.shape[1] == hd and torch.equal(rcatT.t().contiguous(), rcat)
+    out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, scale, need_tables=True)
+    assert tables is None and out.shape == (B * L, H * hd)
+    q64 = qkv.double().clone().requires_grad_(True)
+    rh64 = rcat[:nh].double().clone().requires_grad_(True)
+    rw64 = rcat[nh:nh + nw].double().clone().requires_grad_(True)
+    ref, lse_ref = attn_reference(q64, rh64, rw64, B, L, H, Hp, Wp, scale)
+    e_o, e_l = relerr(out.float(), ref.detach()), relerr(lse, lse_ref.detach())
+    assert e_l < (1e-5 if T == torch.float32 else 2e-3), (e_o, e_l)
+    assert e_o < (2e-5 if T == torch.float32 else 1.2e-2), (e_o, e_l)
+    dqkv, drcat = ops.attn_bwd(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, scale)
+    ref.backward(dout.double())
+    D = H * hd
+    tol = 5e-5 if T == torch.float32 else 1.6e-2
+    errs = dict(dq=relerr(dqkv[:, :D].float(), q64.grad[:, :D]), dk=relerr(dqkv[:, D:2 * D].float(), q64.grad[:, D:2 * D]),
+                dv=relerr(dqkv[:, 2 * D:].float(), q64.grad[:, 2 * D:]), drh=relerr(drcat[:nh], rh64.grad),
+                drw=relerr(drcat[nh:nh + nw], rw64.grad))
+    assert max(errs.values()) < tol, errs
+    assert drcat.shape == (rcat.shape[0], hd) and (drcat.shape[0] == nh + nw or float(drcat[nh + nw:].abs().max()) == 0.0)
+    # same input twice -> the same bits (no atomics on a float accumulation order that varies)
+    out2, lse2 = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, scale)
+    assert torch.equal(out, out2) and torch.equal(lse, lse2)
 
 
 def test_attn_fwd_spiked_key_online_softmax():
@@ -531,13 +572,14 @@ def test_gemm256_epilogues_bitstable_beside_concurrent_mfma_kernels():
     assert bad == 0, "%d of 1000 runs differ" % bad
 
 
+@pytest.mark.parametrize("P", [16, 14])
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("seggpt", [False, True])
-def test_patch_embed_and_token_assembly_in_isolation(T, seggpt):
+def test_patch_embed_and_token_assembly_in_isolation(T, seggpt, P):
     """pa_patch_embed_fwd / pa_patch_embed_wgrad alone: Conv2d(3, D, 16, 16) as an im2col GEMM with the token
     assembly in its epilogue (util/vitdet_utils.py:182-186; models_painter.py:387-409: mask token on the masked target patches, segment
     tokens, abs pos; models_seggpt.py:415-420: type tokens) against torch's conv2d in fp64, and the weight gradient against autograd."""
-    B, Hp, Wp, P, D = 2, 4, 6, 16, 128
+    B, Hp, Wp, D = 2, 4, 6, 128          # P = 14 (ViT-H/14): K = 588 is no multiple of 8 -> the generic gather + the zero-padded weight pack
     L = Hp * Wp
     imgs, tgts = gen((B, 3, Hp * P, Wp * P), 1), gen((B, 3, Hp * P, Wp * P), 2)
     w, bias = gen((D, 3, P, P), 3, 0.05), gen((D,), 4, 0.1)
@@ -547,7 +589,9 @@ def test_patch_embed_and_token_assembly_in_isolation(T, seggpt):
     seg_type = torch.tensor([0.0, 1.0], device=DEV)
     mask = (torch.rand(B, L, generator=torch.Generator().manual_seed(11)) < 0.4).to(DEV)
     wq = w.to(T)
-    x = ops.patch_embed_fwd(T, imgs, tgts, wq.reshape(D, -1).contiguous(), bias, mask_token, seg_x, seg_y, pos, mask.to(torch.uint8),
+    wop = ops.patch_weight_pack(w, T, P)
+    assert wop.shape == (D, (3 * P * P + 7) // 8 * 8) and torch.equal(wop[:, :3 * P * P], wq.reshape(D, -1)) and float(wop[:, 3 * P * P:].float().abs().sum()) == 0.0
+    x = ops.patch_embed_fwd(T, imgs, tgts, wop if P % 8 else wq.reshape(D, -1).contiguous(), bias, mask_token, seg_x, seg_y, pos, mask.to(torch.uint8),
                             tcls if seggpt else None, tins if seggpt else None, seg_type if seggpt else None, B, Hp, Wp, P, D)
     conv = lambda im: torch.nn.functional.conv2d(im.to(T).double(), wq.double(), bias.double(), stride=P).permute(0, 2, 3, 1).reshape(B, L, D)
     ex, ey = conv(imgs), conv(tgts)
@@ -579,8 +623,9 @@ def test_c_abi_of_the_hot_path_rejects_bad_shapes_instead_of_reading_out_of_boun
     p_, s = buf.data_ptr(), torch.cuda.current_stream().cuda_stream
     assert lib.pa_linear_fwd(PA_BF16, 0, p_, 12, p_, p_, p_, None, 16, None, None, 1, 4, 16, 12, s) != 0           # K % 8
     assert lib.pa_linear_fwd(PA_F32, 0, p_, 6, p_, p_, p_, None, 16, None, None, 1, 4, 16, 6, s) != 0              # K % 4
-    assert lib.pa_attn_fwd(PA_BF16, p_, 192, p_, p_, 64, p_, None, 1, 100, 1, 8, 12, 0.125, s) != 0                 # L != Hp * Wp
-    assert lib.pa_attn_fwd(PA_BF16, p_, 192, p_, p_, 64, p_, None, 1, 90, 1, 9, 10, 0.125, s) != 0                  # grid not a multiple of 4
+    assert lib.pa_attn_fwd(PA_BF16, p_, 192, p_, p_, 64, p_, None, 1, 100, 1, 8, 12, 64, 0.125, s) != 0             # L != Hp * Wp
+    assert lib.pa_attn_fwd(PA_BF16, p_, 192, p_, p_, 64, p_, None, 1, 90, 1, 9, 10, 64, 0.125, s) != 0              # grid not a multiple of 4
+    assert lib.pa_attn_fwd(PA_BF16, p_, 288, p_, p_, 96, p_, None, 1, 96, 1, 8, 12, 96, 0.125, s) != 0              # head_dim the kernels are not built for
     assert lib.pa_layernorm_fwd(PA_BF16, p_, 6, p_, p_, 1e-6, p_, 6, p_, p_, 4, 6, s) != 0                          # D % 4
     assert lib.pa_debug_set(99, 1) != 0
     assert lib.pa_attn_set_generation(7) != 0 and lib.pa_attn_set_generation(4) != 0        # the retired builds are gone

@@ -24,12 +24,18 @@ def build(cfg, seed, dtype, train=False):
     m = cls(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
             drop_path_rate=0.1, window_size=14, qkv_bias=True, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
             window_block_indexes=([0, 1], [3, 4]), residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat",
-            decoder_embed_dim=cfg.decoder_embed_dim, loss_func="smoothl1", compute_dtype=dtype)
+            decoder_embed_dim=cfg.decoder_embed_dim, loss_func=cfg.loss_func, compute_dtype=dtype)
+    assert tuple(m._cfg.taps) == tuple(cfg.taps) and m._cfg.merge_idx == cfg.merge_idx
     P = O.random_params(cfg, seed)
     missing = m.load_state_dict(P, strict=True)
     m = m.cuda()
     m.train(train)
     return m, P
+
+
+# gate on the sampled bf16 gradients of the ViT-L fixtures (every 997th element of every tensor against the unmodified reference's fp32
+# gradient, max|a - b| / max|b| per tensor): 1.5 x the largest value measured on MI355X, printed by the tests (pytest -s)
+BF16_SAMPLE_GATE = 1.0e-1
 
 
 def run_painter(m, cfg, batch, seed_x, mask_kind, backward=True):
@@ -154,7 +160,9 @@ def test_vit_large_fp32_vs_reference_golden():
     stride = int(fx[case + "pred_stride"])
     assert G.rel_err(flat[::stride], fx[case + "pred_sample"]) < 1e-3
     assert abs(float(flat.double().norm()) - float(fx[case + "pred_norm"])) < 1e-4 * float(fx[case + "pred_norm"])
-    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-3, 1e-3, 1e-3)
+    rep = []
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-3, 1e-3, 1e-3, sample_rtol=1e-3, report=rep)
+    print("ViT-L B=1 fp32: worst sampled-gradient rel-max error %.3e (%s) over %d tensors" % (max(rep) + (len(rep),)))
 
 
 def test_vit_large_bf16_loss_and_pred_yardstick():
@@ -167,7 +175,9 @@ def test_vit_large_bf16_loss_and_pred_yardstick():
     flat = pred.reshape(-1).cpu()
     stride = int(fx[case + "pred_stride"])
     assert G.rel_fro(flat[::stride], fx[case + "pred_sample"]) < 3e-2      # reference's own bf16 deviation: 1e-2
-    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-1, 5e-2, 1e-1)
+    rep = []
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-1, 5e-2, 1e-1, sample_rtol=BF16_SAMPLE_GATE, report=rep)
+    print("ViT-L B=1 bf16: worst sampled-gradient rel-max error %.3e (%s) over %d tensors" % (max(rep) + (len(rep),)))
 
 
 def _vitl_b8_case(dtype):
@@ -193,7 +203,9 @@ def test_vit_large_b8_train_fp32_vs_reference_golden():
     assert abs(loss.item() - ref_loss) < 1e-4 * abs(ref_loss), (loss.item(), ref_loss)
     for b_ in range(8):
         assert G.rel_err(ps[b_], fx[case + "pred_sample"][b_]) < 1e-3, b_
-    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-3, 1e-3, 1e-3)
+    rep = []
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-3, 1e-3, 1e-3, sample_rtol=1e-3, report=rep)
+    print("ViT-L B=8 train fp32: worst sampled-gradient rel-max error %.3e (%s) over %d tensors" % (max(rep) + (len(rep),)))
 
 
 def test_vit_large_b8_train_bf16_vs_reference_golden():
@@ -205,7 +217,9 @@ def test_vit_large_b8_train_bf16_vs_reference_golden():
     assert abs(loss.item() - ref_loss) < 2e-3 * abs(ref_loss), (loss.item(), ref_loss)
     worst = max(G.rel_fro(ps[b_], fx[case + "pred_sample"][b_]) for b_ in range(8))
     assert worst < 3e-2, worst
-    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-1, 5e-2, 1e-1)
+    rep = []
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-1, 5e-2, 1e-1, sample_rtol=BF16_SAMPLE_GATE, report=rep)
+    print("ViT-L B=8 train bf16 (the timed configuration): worst sampled-gradient rel-max error %.3e (%s) over %d tensors" % (max(rep) + (len(rep),)))
 
 
 def test_seggpt_vit_large_n32_ensemble_and_hipgraph_vs_reference_golden():
@@ -338,3 +352,106 @@ def test_two_forwards_before_one_backward_and_interleaved_modules(dtype):
         else:
             assert float((g - ref).abs().max()) <= 1e-6 * float(ref.abs().max().clamp_min(1e-12)) + 1e-12
     assert all(p.grad is not None for p in other.parameters())
+
+
+# ------------------------------------------------------------------------------------------ ViT-H/14-shaped configurations
+def test_h14_fp32_vs_reference_golden_and_oracle():
+    """head_dim 80 / patch 14 (BASELINE configs[4]'s arithmetic) at the one depth the UNMODIFIED reference can run it (24: its hard-coded
+    taps are the generalised ones there), fixture tests/golden/painter_h14.npz: loss, pred, mask, every gradient; then the oracle at
+    run time, every gradient tensor in full."""
+    fx = G.load("painter_h14.npz")
+    case, cfg = "h14_rand/", O.h14_small_config(depth=24)
+    m, P = build(cfg, 31, "fp32")
+    loss, pred, mo, valid_d = run_painter(m, cfg, 2, 41, "random")
+    ref_loss = float(fx[case + "loss"])
+    assert abs(loss.item() - ref_loss) < 1e-4 * abs(ref_loss), (loss.item(), ref_loss)
+    assert G.rel_err(pred.cpu(), fx[case + "pred"]) < 2e-4
+    assert np.array_equal(mo.cpu().numpy(), fx[case + "mask_out"])
+    rep = []
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-3, 1e-3, 1e-3, report=rep)
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    imgs, tgts, mask, valid = O.synthetic_batch(cfg, 2, 41, "random")
+    lo, po, _ = O.forward(Pg, cfg, imgs, tgts, mask, valid)
+    lo.backward()
+    worst = max((G.rel_fro(p.grad.cpu(), Pg[n].grad), n) for n, p in m.named_parameters())
+    assert worst[0] < 1e-3, worst
+    print("h14 fp32: worst sampled-gradient rel-max %.3e (%s); worst full-tensor rel-fro vs oracle %.3e (%s)" % (max(rep) + worst))
+
+
+def test_h14_train_mode_droppath_vs_reference_golden():
+    fx = G.load("painter_h14.npz")
+    case, cfg = "h14_train/", O.h14_small_config(depth=24)
+    m, _ = build(cfg, 32, "fp32", train=True)
+    flat = torch.from_numpy(fx[case + "drop_scales_flat"])
+    chunks = list(torch.split(flat, [int(x) for x in fx[case + "drop_scales_len"]]))
+    m._drop_override = [(None, None)] + [(chunks[2 * i].cuda().contiguous(), chunks[2 * i + 1].cuda().contiguous()) for i in range(cfg.depth - 1)]
+    loss, pred, _, _ = run_painter(m, cfg, 2, 42, "half")
+    ref_loss = float(fx[case + "loss"])
+    assert abs(loss.item() - ref_loss) < 1e-4 * abs(ref_loss), (loss.item(), ref_loss)
+    assert G.rel_err(pred.cpu(), fx[case + "pred"]) < 2e-4
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 1e-3, 1e-3, 1e-3)
+
+
+def test_h14_bf16_vs_reference_golden():
+    fx = G.load("painter_h14.npz")
+    case, cfg = "h14_rand/", O.h14_small_config(depth=24)
+    m, _ = build(cfg, 31, "bf16")
+    loss, pred, _, _ = run_painter(m, cfg, 2, 41, "random")
+    ref_loss = float(fx[case + "loss"])
+    assert abs(loss.item() - ref_loss) < 2e-3 * abs(ref_loss), (loss.item(), ref_loss)
+    assert G.rel_fro(pred.cpu(), fx[case + "pred"]) < 3e-2
+    rep = []
+    G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], 8e-2, 5e-2, 8e-2, sample_rtol=BF16_SAMPLE_GATE, report=rep)
+    print("h14 bf16: worst sampled-gradient rel-max %.3e (%s)" % max(rep))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_h14_generalised_taps_other_depth_vs_oracle(dtype):
+    """depth 16 (taps 3, 7, 11, 15 = depth/4*k - 1, the extension ViT-H/14's depth 32 needs: SURVEY.md 8d note H).  No reference golden
+    exists for a depth other than 24 -- the oracle with the same generalised taps is the checker; every block must receive gradient."""
+    cfg = O.h14_small_config(depth=16)
+    assert cfg.taps == (3, 7, 11, 15)
+    m, P = build(cfg, 33, dtype)
+    loss, pred, _, _ = run_painter(m, cfg, 2, 43, "random")
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    imgs, tgts, mask, valid = O.synthetic_batch(cfg, 2, 43, "random")
+    lo, po, _ = O.forward(Pg, cfg, imgs, tgts, mask, valid)
+    lo.backward()
+    tol_l, tol_p, tol_g = (1e-4, 2e-4, 1e-3) if dtype == "fp32" else (2e-3, 3e-2, 8e-2)
+    assert abs(loss.item() - lo.item()) < tol_l * abs(lo.item())
+    assert G.rel_fro(pred.cpu(), po.detach()) < tol_p
+    worst = max((G.rel_fro(p.grad.cpu(), Pg[n].grad), n) for n, p in m.named_parameters())
+    assert worst[0] < tol_g, worst
+    assert all(float(p.grad.abs().max()) > 0 for n, p in m.named_parameters() if "blocks.15." in n and "bias" not in n)
+
+
+# ------------------------------------------------------------------------------------------ loss variants, pose weighting
+@pytest.mark.parametrize("loss_func", ["l1", "l2", "l1l2", "smoothl1"])
+def test_loss_variants_and_pose_valid_weight_vs_oracle(loss_func):
+    """Painter/models_painter.py:452-460: the four loss_func branches, with a `valid` map that carries the pose task's weight 10.0
+    (data/pairdataset.py:172) on a region, zeros on another and ones elsewhere: loss, pred and every parameter gradient (fp32 build)
+    against the oracle's autograd."""
+    import dataclasses
+    cfg = dataclasses.replace(O.small_config(), loss_func=loss_func)
+    m, P = build(cfg, 51, "fp32")
+    imgs, tgts, mask, valid = O.synthetic_batch(cfg, 2, 61, "random")
+    valid[0, :, 70:110, 8:40] = 10.0
+    valid[1, :, 64:90, :] = 0.0
+    for p in m.parameters():
+        p.grad = None
+    vd = valid.clone().cuda()
+    loss, pred, _ = m(imgs.cuda(), tgts.cuda(), bool_masked_pos=mask.reshape(2, *cfg.grid).cuda(), valid=vd)
+    loss.backward()
+    torch.cuda.synchronize()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    vo = valid.clone()
+    lo, po, _ = O.forward(Pg, cfg, imgs, tgts, mask, vo)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-4 * abs(lo.item()), (loss.item(), lo.item())
+    assert torch.equal(vd.cpu(), vo)                                   # the in-place ignore rule saw the same `valid`
+    worst = max((G.rel_fro(p.grad.cpu(), Pg[n].grad), n) for n, p in m.named_parameters())
+    assert worst[0] < 1e-3, worst
+    if loss_func != "smoothl1":                                        # the weighting really matters: dropping the 10.0 changes the loss
+        v1 = valid.clone().clamp_max(1.0)
+        l1, _, _ = O.forward(P, cfg, imgs, tgts, mask, v1)
+        assert abs(l1.item() - lo.item()) > 1e-3 * abs(lo.item())

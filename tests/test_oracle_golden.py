@@ -18,13 +18,14 @@ def _drop_scales(fx, prefix, cfg, batch):
     return chunks
 
 
-@pytest.mark.parametrize("case,batch,mask_kind,seed_p,seed_x", [
-    ("painter_half/", 2, "half", 1, 1234),
-    ("painter_rand/", 3, "random", 3, 99),
+@pytest.mark.parametrize("fixture,case,batch,mask_kind,seed_p,seed_x", [
+    ("painter_tiny.npz", "painter_half/", 2, "half", 1, 1234),
+    ("painter_tiny.npz", "painter_rand/", 3, "random", 3, 99),
+    ("painter_h14.npz", "h14_rand/", 2, "random", 31, 41),        # head_dim 80, patch 14 (ViT-H/14's arithmetic) at the reference's depth 24
 ])
-def test_oracle_matches_reference_golden_painter(case, batch, mask_kind, seed_p, seed_x):
-    fx = G.load("painter_tiny.npz")
-    cfg = O.tiny_config()
+def test_oracle_matches_reference_golden_painter(fixture, case, batch, mask_kind, seed_p, seed_x):
+    fx = G.load(fixture)
+    cfg = O.h14_small_config(depth=24) if fixture == "painter_h14.npz" else O.tiny_config()
     P = {k: v.clone().requires_grad_(True) for k, v in O.random_params(cfg, seed_p).items()}
     imgs, tgts, mask, valid = O.synthetic_batch(cfg, batch, seed_x, mask_kind)
     loss, pred, m = O.forward(P, cfg, imgs, tgts, mask.reshape(batch, *cfg.grid), valid)
@@ -36,13 +37,14 @@ def test_oracle_matches_reference_golden_painter(case, batch, mask_kind, seed_p,
     G.check_grad_digests(fx, case, [(k, v.grad) for k, v in P.items()], 1e-4, 1e-5, 1e-4)
 
 
-def test_oracle_train_mode_droppath_matches_reference():
+@pytest.mark.parametrize("fixture,case,seed_p,seed_x,mask_kind", [("painter_tiny.npz", "painter_train/", 5, 11, "random"),
+                                                                  ("painter_h14.npz", "h14_train/", 32, 42, "half")])
+def test_oracle_train_mode_droppath_matches_reference(fixture, case, seed_p, seed_x, mask_kind):
     """timm 0.3.2 DropPath semantics with the reference's recorded per-sample factors."""
-    fx = G.load("painter_tiny.npz")
-    case = "painter_train/"
-    cfg = O.tiny_config()
-    P = {k: v.clone().requires_grad_(True) for k, v in O.random_params(cfg, 5).items()}
-    imgs, tgts, mask, valid = O.synthetic_batch(cfg, 2, 11, "random")
+    fx = G.load(fixture)
+    cfg = O.h14_small_config(depth=24) if fixture == "painter_h14.npz" else O.tiny_config()
+    P = {k: v.clone().requires_grad_(True) for k, v in O.random_params(cfg, seed_p).items()}
+    imgs, tgts, mask, valid = O.synthetic_batch(cfg, 2, seed_x, mask_kind)
     chunks = _drop_scales(fx, case, cfg, 2)
     # the reference draws an independent mask for the attn and mlp branch; the oracle block() takes
     # one factor per block, so fold the two draws through a custom per-branch call.
@@ -148,3 +150,20 @@ def test_ignore_rule_mutates_valid_in_place():
     with torch.no_grad():
         O.forward(P, cfg, imgs, tgts, mask, valid)
     assert valid[0].min() == 1.0 and valid[1].max() == 0.0
+
+
+def test_generalised_taps_are_the_reference_taps_at_depth_24():
+    """models_painter.py:416 hard-codes [5, 11, 17, 23]; the extension for other depths (ViT-H/14: depth 32) must reduce to it."""
+    assert O.generalised_taps(24) == (5, 11, 17, 23) == O.vit_large_config().taps
+    assert O.generalised_taps(32) == (7, 15, 23, 31) == O.vit_huge_config().taps
+    from painter_amd.engine import HotPathConfig
+    from painter_amd import hostmath
+    for depth in (16, 24, 32):
+        c = HotPathConfig(img_size=(112, 56), patch_size=14, embed_dim=160, depth=depth, num_heads=2, mlp_ratio=4, decoder_embed_dim=64,
+                          pretrain_img_size=224, pretrain_use_cls_token=True, use_rel_pos=True, ln_eps=1e-6, loss_func="smoothl1",
+                          seggpt=False, drop_path_rate=0.1)
+        assert tuple(c.taps) == O.generalised_taps(depth) and c.merge_idx == 2
+    # the position-grid resize operator of patch 14 (16 x 16 pre-training grid -> 64 x 32 tokens) is pinned to F.interpolate like patch 16's
+    Pm = torch.randn(1, 257, 8)
+    M = torch.from_numpy(hostmath.abs_pos_operator(16, 64, 32))
+    assert G.rel_err(M @ Pm[0, 1:], O.get_abs_pos(Pm, True, (64, 32)).reshape(64 * 32, 8)) < 1e-5

@@ -32,8 +32,8 @@ def main():
     nrp = lib.pa_relpos_rows_padded(Hp, Wp)
     dG = torch.randn(R, H * nrp, generator=g).to(T).to(DEV)
     drcat = torch.empty((nrp, 64), dtype=torch.float32, device=DEV)
-    ws = ops.workspace(lib.pa_attn_bwd_relpos_workspace_bytes(1, B, L, H, Hp, Wp), qkv.device)
-    f = lambda: check(lib.pa_attn_bwd_relpos(1, dG.data_ptr(), qkv.data_ptr(), qkv.stride(0), drcat.data_ptr(), ws.data_ptr(), B, L, H, Hp, Wp, ops.stream()), "x")
+    ws = ops.workspace(lib.pa_attn_bwd_relpos_workspace_bytes(1, B, L, H, Hp, Wp, 64), qkv.device)
+    f = lambda: check(lib.pa_attn_bwd_relpos(1, dG.data_ptr(), qkv.data_ptr(), qkv.stride(0), drcat.data_ptr(), ws.data_ptr(), B, L, H, Hp, Wp, 64, ops.stream()), "x")
     print("relpos_grad %.1f us" % timeit(f))
     x = torch.randn(R, 1024, generator=g).to(DEV)
     gam, bet = torch.ones(1024, device=DEV), torch.zeros(1024, device=DEV)
