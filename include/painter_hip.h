@@ -149,6 +149,9 @@ int pa_merge_bwd(int dtype, const float* dmerged, float* dx, void* dxT, const fl
 int pa_scale_cast(int dtype, const float* in, void* out, const float* rowscale, int rows_per_sample, int64_t rows, int D,
                   hipStream_t stream);
 int pa_cast_bf16(const float* in, void* out, int64_t n, hipStream_t stream);
+/* diagnostics only (tools/gradsync_overlap.py): scratch = 0.5 * (scratch + src), `passes` times, on exactly `nblocks` persistent
+ * workgroups -- a stand-in for the CU / HBM footprint of a ring all-reduce with `nblocks` channels.  Never on the product path. */
+int pa_debug_rmw(const float* src, float* scratch, int64_t n, int passes, int nblocks, hipStream_t stream);
 /* SegGPT cross-prompt feature ensemble + residual (models_seggpt.py:220-232): x1 = x0 + ens(a), groups of `group` samples */
 int pa_ensemble_resid(const float* x0, const float* a, float* x1, int batch, int group, int L, int D, hipStream_t stream);
 

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_dkv_kernel(const T* __restri
     RowStage<T, NT, HD> qs, dos;
     TrStage<T, HD> qts, dots;
     const int NAUX = (TS + 2) * 8;                       // 16-B chunks of the aux tile
-    constexpr int CAUX = 3;                              // up to 3 * NT chunks (TS + 2 <= 3 * NT / 8)
+    constexpr int CAUX = HD == 64 ? 3 : 4;               // up to CAUX * NT chunks: TS + 2 <= 96 (HD 64: the 56 x 28 grid) / 128 (ViT-H/14: 64 x 32 -> 98)
     uint4 ra[CAUX];
     const int ntile = L / 32;
     auto load_all = [&](int j) {
@@ -500,7 +500,7 @@ static int attn_bwd_t(const T* qkv, int64_t ldq, const T* rcat, const T* rcatT, 
         size_t smem = 2 * (size_t)(2 * KV::KB + 2 * KV::VB + AUXB);
         const size_t stg = (size_t)NW * 2 * 32 * HD * sizeof(T);
         if (smem < stg) smem = stg;
-        if (smem > 160 * 1024 || (TS + 2) * 8 > 3 * NW * 64) return (int)hipErrorInvalidValue;
+        if (smem > 160 * 1024 || (TS + 2) * 8 > (HD == 64 ? 3 : 4) * NW * 64) return (int)hipErrorInvalidValue;
         auto kern = attn_bwd_dkv_kernel<T, NW, HD>;
         static bool done = false;
         if (!done) {

@@ -434,3 +434,23 @@ extern "C" int pa_decoder_tail_bwd_pointwise(int dtype, const float* dpred, cons
     if (e) return e;
     return pa_slab_reduce(part, grads, TAILP, nb, TAILP, 0, st);
 }
+
+// ------------------------------------------------------------------------------- diagnostics: a stand-in for a collective's kernel
+// scratch[i] = 0.5 * (scratch[i] + src[i]), `passes` times, on exactly `nblocks` persistent workgroups of 256 threads: the HBM traffic
+// (12 B per element per pass) and CU footprint of a ring all-reduce step with `nblocks` channels, without touching the gradient it
+// reads.  Used by tools/gradsync_overlap.py to price the backward's loss of CUs / bandwidth to RCCL on a single-GPU box, where a
+// 1-rank group launches no ring kernel at all.  Never on the product path.
+__global__ __launch_bounds__(256) void debug_rmw_kernel(const float* __restrict__ src, float* __restrict__ scratch, size_t n4, int passes) {
+    for (int p = 0; p < passes; ++p)
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+            const float4 a = reinterpret_cast<const float4*>(src)[i];
+            float4 b = reinterpret_cast<float4*>(scratch)[i];
+            b.x = 0.5f * (a.x + b.x); b.y = 0.5f * (a.y + b.y); b.z = 0.5f * (a.z + b.z); b.w = 0.5f * (a.w + b.w);
+            reinterpret_cast<float4*>(scratch)[i] = b;
+        }
+}
+extern "C" int pa_debug_rmw(const float* src, float* scratch, int64_t n, int passes, int nblocks, hipStream_t st) {
+    if (n % 4 || nblocks < 1 || passes < 1) return (int)hipErrorInvalidValue;
+    PA_LAUNCH(debug_rmw_kernel, dim3(nblocks), dim3(256), 0, st, src, scratch, (size_t)(n / 4), passes);
+    LAUNCH_CHECK();
+}

@@ -272,15 +272,16 @@ class HotPath:
 
         filt = getattr(self, "side_filter", None)          # diagnostics: {"dec","fc2","fc1","proj","qkv"} subsets, "nocolsum", "nowgrad"
 
-        def param_grads(wname, bname, dy, x):
-            """G[wname] = dy^T.x, G[bname] = colsum(dy) -- on the side stream when enabled."""
+        def param_grads(wname, bname, dy, x, bout=None):
+            """G[wname] = dy^T.x, G[bname] = colsum(dy) (into `bout`, a slice of the block's flat small-gradient buffer, when given)
+            -- on the side stream when enabled."""
             tag = "dec" if wname.startswith("decoder") else wname.split(".")[-2]
             if side is None or (filt is not None and tag not in filt):
                 G[wname] = ops.linear_wgrad(dy, x)
-                G[bname] = ops.colsum(dy)
+                G[bname] = ops.colsum(dy, out=bout)
                 return
             if filt is not None and "nocolsum" in filt:
-                G[bname] = ops.colsum(dy)
+                G[bname] = ops.colsum(dy, out=bout)
             if filt is not None and "nowgrad" in filt:
                 G[wname] = ops.linear_wgrad(dy, x)
             side.wait_stream(main)                 # dy (and x) are enqueued on main
@@ -288,7 +289,7 @@ class HotPath:
                 if wname not in G:
                     G[wname] = ops.linear_wgrad(dy, x)
                 if bname not in G:
-                    G[bname] = ops.colsum(dy)
+                    G[bname] = ops.colsum(dy, out=bout)
             dy.record_stream(side)                 # the allocator must not hand these out again before the side stream is done
             x.record_stream(side)
             if _DBG_KEEP:
@@ -309,17 +310,19 @@ class HotPath:
                 main.wait_stream(side)
             return r
 
-        def ready(names):
+        def ready(names, flat=None):
+            """flat: one contiguous fp32 buffer that already holds every small gradient of `names` (they are views of it): it is
+            exchanged as ONE message in place -- no flattening copy on the side stream."""
             if sync is None:
                 return
             if side is None:
-                sync.ready(G, names)
+                sync.ready(G, names, flat=flat)
                 return
             side.wait_stream(main)                 # the bucket's gradients come from both streams
             for n in names:                        # main-stream allocations (LayerNorm / rel-pos / tail gradients) are read by the
-                G[n].record_stream(side)           # side stream's flattening copy: keep the allocator from recycling them early
+                G[n].record_stream(side)           # side stream's exchange: keep the allocator from recycling them early
             with torch.cuda.stream(side):
-                sync.ready(G, names)
+                sync.ready(G, names, flat=flat)
 
         dpred = ops.loss_bwd(S.pred, S.tgts, S.valid, S.mask, dloss, S.loss_out, c.P, c.loss_func)
         w1 = P["decoder_pred.3.weight"].reshape(3, c.dec)
@@ -348,6 +351,14 @@ class HotPath:
             S.blocks[i] = None
             R = Bc * L
             ds_a, ds_m = (None, None) if S.drop is None else S.drop[i]
+            # the block's small gradients (LayerNorm affine, the four biases, the rel-pos tables) live in ONE flat buffer so that the
+            # gradient exchange sends them as one message without a flattening copy: [norm1 g,b | norm2 g,b | qkv.b | proj.b | fc1.b | fc2.b | d rcat]
+            nrp, hd = rcat.shape
+            sizes = [2 * D, 2 * D, 3 * D, D, c.hidden, D, nrp * hd]
+            flat = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
+            if side is not None:
+                flat.record_stream(side)
+            fl = dict(zip(("n1", "n2", "qkv", "proj", "fc1", "fc2", "rel"), torch.split(flat, sizes)))
             # dyT = bf16(ds_m * dx) is emitted by the kernel that produces the final dx of this block's output: the tap
             # LayerNorm backward, block i+1's norm1 backward (dyT_next), or the stream-merge backward
             if i in c.taps:
@@ -362,35 +373,35 @@ class HotPath:
             else:
                 dyT = dyT_next
             # ---- MLP branch: x2 = x1 + s_m * fc2(gelu(fc1(LN2(x1))))
-            param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dyT, act)
+            param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dyT, act, fl["fc2"])
             tr("%d.dyT" % i, dyT)
             dpre = ops.linear_dgrad(dyT, self.w(pre + "mlp.fc2.weight", P), pre=hpre)
             tr("%d.dpre" % i, dpre)
-            param_grads(pre + "mlp.fc1.weight", pre + "mlp.fc1.bias", dpre, ln2)
+            param_grads(pre + "mlp.fc1.weight", pre + "mlp.fc1.bias", dpre, ln2, fl["fc1"])
             dln2 = ops.linear_dgrad(dpre, self.w(pre + "mlp.fc1.weight", P))
             tr("%d.dln2" % i, dln2)
             del dpre
             # dyT may still be read by the side stream: the attention branch's dY gets its own buffer
             dyA = torch.empty_like(dyT) if side is not None else dyT
             dx, gb = ops.layernorm_bwd(dln2, x1, mean2, rstd2, P[pre + "norm2.weight"], dres=dx, dx=dx, dxT=dyA,
-                                       rowscale=ds_a, rows_per_sample=L)
+                                       rowscale=ds_a, rows_per_sample=L, gb=fl["n2"].view(2, D))
             del dyT
             tr("%d.dx_ln2" % i, dx); tr("%d.dyA" % i, dyA); tr("%d.gb2" % i, gb)
             G[pre + "norm2.weight"], G[pre + "norm2.bias"] = gb[0], gb[1]
             # ---- attention branch: x1 = x0 + s_a * proj(attn(LN1(x0)))
-            param_grads(pre + "attn.proj.weight", pre + "attn.proj.bias", dyA, ao)
+            param_grads(pre + "attn.proj.weight", pre + "attn.proj.bias", dyA, ao, fl["proj"])
             dao = ops.linear_dgrad(dyA, self.w(pre + "attn.proj.weight", P), out=dln2)
             tr("%d.dao" % i, dao)
             del dyA
             rcatT = self.relpos(pre, P, True)
             dqkv, dG = ops.attn_bwd_core(qkv, rcat, rcatT, ao, dao, lse, Bc, L, c.heads, c.Hp, c.Wp, c.scale, tables=atab)
-            drcat = on_side(lambda: ops.attn_bwd_relpos(dG, qkv, rcat.shape[0], Bc, L, c.heads, c.Hp, c.Wp), dG, qkv)
+            drcat = on_side(lambda: ops.attn_bwd_relpos(dG, qkv, nrp, Bc, L, c.heads, c.Hp, c.Wp, out=fl["rel"].view(nrp, hd)), dG, qkv)
             del dG
             tr("%d.dqkv" % i, dqkv)
             nh, nw = 2 * c.Hp - 1, 2 * c.Wp - 1
             G[pre + "attn.rel_pos_h"] = drcat[:nh]
             G[pre + "attn.rel_pos_w"] = drcat[nh:nh + nw]
-            param_grads(pre + "attn.qkv.weight", pre + "attn.qkv.bias", dqkv, ln1)
+            param_grads(pre + "attn.qkv.weight", pre + "attn.qkv.bias", dqkv, ln1, fl["qkv"])
             dln1 = ops.linear_dgrad(dqkv, self.w(pre + "attn.qkv.weight", P), out=dao)
             del dqkv
             nxt = i - 1
@@ -399,11 +410,11 @@ class HotPath:
                 dyT_next = torch.empty((R, D), dtype=T, device=dev)
             ds_next = None if (S.drop is None or nxt < 0) else S.drop[nxt][1]
             dx, gb = ops.layernorm_bwd(dln1, x0, mean1, rstd1, P[pre + "norm1.weight"], dres=dx, dx=dx, dxT=dyT_next,
-                                       rowscale=ds_next if dyT_next is not None else None, rows_per_sample=L)
+                                       rowscale=ds_next if dyT_next is not None else None, rows_per_sample=L, gb=fl["n1"].view(2, D))
             G[pre + "norm1.weight"], G[pre + "norm1.bias"] = gb[0], gb[1]
             tr("%d.dx_ln1" % i, dx)
             del x0, ln1, qkv, ao, x1, ln2, hpre, act, atab
-            ready([n for n in G if n.startswith(pre)])
+            ready([n for n in G if n.startswith(pre)], flat=flat)
         G["norm.weight"], G["norm.bias"] = dnorm[0], dnorm[1]
         # ---- token assembly + patch embed
         dpe, sums = ops.tokens_bwd(T, dx, S.mask, B, L, D)

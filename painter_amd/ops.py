@@ -126,12 +126,14 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype, out=None):
     return out, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, dx=None, dxT=None, rowscale=None, rows_per_sample=1):
-    """-> dx (f32, = dres + LN'(dy)), dgamma_dbeta [2, D]."""
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, dx=None, dxT=None, rowscale=None, rows_per_sample=1, gb=None):
+    """-> dx (f32, = dres + LN'(dy)), dgamma_dbeta [2, D] (written into `gb` when given)."""
     R, D = x.shape
     if dx is None:
         dx = torch.empty((R, D), dtype=torch.float32, device=x.device)
-    gb = torch.empty((2, D), dtype=torch.float32, device=x.device)
+    if gb is None:
+        gb = torch.empty((2, D), dtype=torch.float32, device=x.device)
+    assert gb.shape == (2, D) and gb.is_contiguous() and gb.dtype == torch.float32
     ws = workspace(lib.pa_layernorm_bwd_workspace_bytes(R, D), x.device)
     check(lib.pa_layernorm_bwd(code(dy.dtype), p(dy), dy.stride(0), p(x), x.stride(0), p(mean), p(rstd), p(gamma),
                                p(dres), p(dx), dx.stride(0), p(dxT), 0 if dxT is None else dxT.stride(0), p(rowscale),

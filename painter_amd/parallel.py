@@ -52,10 +52,12 @@ class GradSync:
         work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return work, ((1.0 / self.world_size) if self.average else None)    # gloo (CPU tests) has no AVG
 
-    def ready(self, G, names):
+    def ready(self, G, names, flat=None):
         """Gradients `names` of dict G are enqueued on the current stream: start their all-reduce.  Weight matrices (>= 1 M
         elements: 4-268 MB messages, large enough to run at link bandwidth) are reduced in place; the bucket's small tensors
-        (biases, LayerNorm, rel-pos tables) are flattened into one message and replaced by views of it."""
+        (biases, LayerNorm, rel-pos tables) go as ONE message: `flat` when the producer wrote them into one contiguous buffer
+        (the engine does, per transformer block: they are views of it, nothing is copied), otherwise they are flattened into a
+        fresh buffer here and replaced by views of it."""
         if self.world_size == 1 and not _SELFTEST:
             return
         small = []
@@ -66,7 +68,12 @@ class GradSync:
                 self._pending.append((work, t, post))
             else:
                 small.append(n)
-        if small:
+        if small and flat is not None:
+            lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
+            assert all(lo <= G[n].data_ptr() and G[n].data_ptr() + G[n].numel() * 4 <= hi for n in small), "flat does not hold every small gradient"
+            work, post = self._reduce(flat)
+            self._pending.append((work, flat, post))
+        elif small:
             ts = [G[n] for n in small]
             flat = torch.cat([t.reshape(-1) for t in ts])
             work, post = self._reduce(flat)

@@ -56,6 +56,27 @@ def _worker(rank, world, port, q):
         ref /= world
         ok &= bool(torch.allclose(G[n], ref, atol=1e-6)) and G[n].shape == torch.Size(s)
     ok &= not hasattr(sync, "set_sync")          # there is no way to skip a micro-step's exchange (replicas would diverge)
+    # the engine's per-block arrangement: the small gradients are views of ONE pre-allocated flat buffer, exchanged in place as one
+    # message (no flattening copy); the big matrix goes in place as before
+    g2 = torch.Generator().manual_seed(500 + rank)
+    flat = torch.randn(7 + 20, generator=g2)
+    big = torch.randn(16, 8, generator=g2)
+    G2 = {"blocks.3.mlp.fc1.bias": flat[:7], "blocks.3.attn.rel_pos_h": flat[7:].view(5, 4), "blocks.3.mlp.fc1.weight": big}
+    ptrs = {n: t.data_ptr() for n, t in G2.items()}
+    sync.ready(G2, list(G2), flat=flat)
+    sync.finish()
+    ref_flat, ref_big = torch.zeros(27), torch.zeros(16, 8)
+    for rk in range(world):
+        gg = torch.Generator().manual_seed(500 + rk)
+        ref_flat += torch.randn(27, generator=gg)
+        ref_big += torch.randn(16, 8, generator=gg)
+    ok &= bool(torch.allclose(flat, ref_flat / world, atol=1e-6)) and bool(torch.allclose(big, ref_big / world, atol=1e-6))
+    ok &= all(G2[n].data_ptr() == ptrs[n] for n in G2)          # still the same views: nothing was copied or re-pointed
+    try:
+        sync.ready({"a": torch.zeros(3)}, ["a"], flat=torch.zeros(3))
+        ok = False                                               # a flat buffer that does not hold the gradient must be refused
+    except AssertionError:
+        pass
     q.put((rank, ok))
     dist.barrier()
     dist.destroy_process_group()
@@ -91,7 +112,11 @@ def _worker_model(rank, world, port, q):
     # replicas start from different seeds (main_train.py:190) and are made identical by the broadcast
     P0 = O.random_params(cfg, 50 + rank)
     holder = torch.nn.ParameterDict({k.replace(".", "/"): torch.nn.Parameter(v) for k, v in P0.items()})
+    versions = [p._version for p in holder.values()]
     parallel.broadcast_parameters(holder)
+    # the broadcast must bump every parameter's version counter: the engine's cached bf16 operand copies are keyed on it (a replica
+    # that ran a forward before the broadcast would otherwise keep multiplying by its old weights)
+    assert all(p._version > v for p, v in zip(holder.values(), versions))
     P0 = {k.replace("/", "."): v.detach() for k, v in holder.items()}
     ref0 = O.random_params(cfg, 50)
     same = all(torch.equal(P0[k], ref0[k]) for k in ref0)

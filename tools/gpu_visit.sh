@@ -1,0 +1,24 @@
+#!/bin/bash
+# One parameterised command list for a GPU visit (replaces round 2's per-visit scripts).  Usage on the box, from the repo root:
+#   bash tools/gpu_visit.sh <section> [<section> ...]      sections: tests newtests bench huge profile pmc overlap ab
+# Everything lands under gpurun_out/<section>*; copy what should be judged into profiles/.
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+HEAD=${PAINTER_AMD_GIT_HEAD:-unknown}
+export PAINTER_AMD_GIT_HEAD=$HEAD
+for s in "$@"; do
+  case $s in
+    tests)     timeout 1500 python -m pytest tests -m gpu -x -q -s > gpurun_out/tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/tests.log ;;
+    newtests)  timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -s -k "head_dim_80 or h14 or loss_variants or patch_embed or vit_large or c_abi" > gpurun_out/newtests.log 2>&1; echo "newtests rc=$?"; tail -15 gpurun_out/newtests.log ;;
+    bench)     timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-600 gpurun_out/bench.json ;;
+    benchfast) timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-optimizer > gpurun_out/benchfast.json 2> gpurun_out/benchfast.err; echo "benchfast rc=$?"; cut -c1-400 gpurun_out/benchfast.json ;;
+    huge)      timeout 900 python bench.py --model vit_huge --steps 5 --warmup 2 --no-cpu-baseline --min-seconds 2 > gpurun_out/bench_huge.json 2> gpurun_out/bench_huge.err; echo "huge rc=$?"; cut -c1-600 gpurun_out/bench_huge.json; tail -3 gpurun_out/bench_huge.err ;;
+    profile)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_two_stream -o two -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_two.log 2>&1
+                PAINTER_AMD_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_one_stream -o one -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_one.log 2>&1); echo "profile done"; ls gpurun_out/prof_one_stream gpurun_out/prof_two_stream 2>/dev/null | head ;;
+    pmc)       (cd /tmp && for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
+                  n=$(echo $c | cut -d' ' -f1); PAINTER_AMD_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/gpurun_out/pmc_$n -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/pmc_$n.log 2>&1; done); echo "pmc done" ;;
+    overlap)   PAINTER_AMD_DDP_SELFTEST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 timeout 600 python tools/gradsync_overlap.py > gpurun_out/overlap.log 2>&1; echo "overlap rc=$?"; tail -12 gpurun_out/overlap.log ;;
+    *)         echo "unknown section $s" ;;
+  esac
+done
