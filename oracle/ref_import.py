@@ -149,6 +149,14 @@ def load_reference_seggpt():
     return _load("ref_models_seggpt", os.path.join(SEGGPT_DIR, "models_seggpt.py"), SEGGPT_DIR)
 
 
+def load_reference_engine_train():
+    """-> the reference module object of Painter/engine_train.py (train_one_epoch, evaluate_pt) together with its own util.misc /
+    util.lr_sched (reachable as module attributes `misc`, `lr_sched`); `wandb` and `torch._six` are stand-ins.  The module only
+    touches the MODEL through its public surface, so any module with that surface -- the reference class or
+    painter_amd.models_painter.Painter -- can be driven by it unchanged."""
+    return _load("ref_engine_train", os.path.join(PAINTER_DIR, "engine_train.py"), PAINTER_DIR)
+
+
 def load_reference_seggpt_engine():
     """-> the reference module object of SegGPT/SegGPT_inference/seggpt_engine.py (cv2 is a stand-in: only inference_video needs it)."""
     return _load("ref_seggpt_engine", os.path.join(SEGGPT_DIR, "seggpt_engine.py"), SEGGPT_DIR)

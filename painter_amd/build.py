@@ -9,8 +9,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-OBJ = os.path.join(HERE, "lib", "obj")
-LIB = os.path.join(HERE, "lib", "libpainter_hip.so")
+OBJ = os.path.join(HERE, "lib", "obj" + ("" if "PA_LIB_NAME" not in os.environ else "_" + os.environ["PA_LIB_NAME"].replace(".", "_")))
+LIB = os.path.join(HERE, "lib", os.environ.get("PA_LIB_NAME", "libpainter_hip.so"))    # PA_LIB_NAME / PA_EXTRA_FLAGS: A/B experiment builds
 ARCH = "gfx950"
 # -fno-slp-vectorize: hipcc (ROCm 7.2) SLP-packs adjacent fp32 adds / muls / fmas into v_pk_*_f32.  On gfx950 a kernel built that
 # way (LayerNorm backward: the packed (s1, s2) row-sum accumulators) returned a wrong s2 for one row in ~1 % of its launches whenever
@@ -20,6 +20,7 @@ ARCH = "gfx950"
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wno-unused-result"]
 if os.environ.get("PA_SLP") != "1":
     FLAGS = FLAGS + ["-fno-slp-vectorize"]
+FLAGS = FLAGS + os.environ.get("PA_EXTRA_FLAGS", "").split()
 # seggpt_io.hip / pair_io.hip reproduce host float arithmetic (numpy, Pillow) bit for bit: no fused multiply-add there.
 EXTRA = {"seggpt_io.hip": ["-ffp-contract=off"], "pair_io.hip": ["-ffp-contract=off"]}
 

@@ -26,7 +26,7 @@ namespace g256 {
 constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
 constexpr int LDS_BYTES = 131072;
 // diagnostics (pa_debug_set): [0] first-round de-phasing in shader cycles, [1] drop epilogue stores, [2] 1 = plain row-major tile order, [3] wgrad workgroup target
-inline int g_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // [4] gemm128 policy override: 0 = PA_GEMM128 / default, 1 + mode otherwise
+inline int g_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // [5] (G256_ILV_AB builds) 1 + ILV schedule override
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
@@ -116,7 +116,14 @@ template <> struct Frag4<true> {
 //   Col col(j)                      per-lane column constants (bias[j..j+7]), loaded once per tile
 //   Row row(i, j)                   per-(row, 8 columns) global inputs (residual, GELU pre-activation), loaded ahead of the stores
 //   store(i, j, lo, hi, col, row, split)   lo = D[i][j..j+3], hi = D[i][j+4..j+7]
-template <bool AMM, bool BMM, class Epi>
+// ILV: how many of a phase's two LDS-DMA pieces are issued INSIDE the phase's MFMA segment instead of in front of its first barrier.
+// Between two barriers one wave row runs its MFMA segment (8 MFMAs = 256 cycles + the fragment wait) while the other runs its
+// load segment (fragment reads, 2 DMA issues at ~60-180 cycles each, the counted vmcnt wait); the barrier interval is the longer of
+// the two, and with both DMA issues in the load segment that segment is the longer one (measured 435 cycles per interval against
+// ~280 for the MFMA segment: 59 % matrix-pipe utilisation in the main loop).  Moving issues between the MFMAs balances the two.
+// The counted wait shrinks by ILV (the pieces of this phase that are not issued yet do not count); every hazard distance of the
+// header comment only grows (a unit is re-staged later, never earlier; it is still waited for >= 1 barrier before its first read).
+template <bool AMM, bool BMM, int ILV, class Epi>
 __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag, uint32_t lda, const bf16* __restrict__ Bg,
                                                       uint32_t ldb, Epi epi, int M, int N, int ktiles, int ktiles_per_split,
                                                       int tiles_n, int stagger, int order) {
@@ -182,16 +189,17 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
     const unsigned char* bbase = reinterpret_cast<const unsigned char*>(Bg) + (size_t)kt0 * b_step;
     unsigned char* const dma_dst = smem + wv * 1024;
 
-    auto stage_a = [&](int sub, int stage, int kt) {
+    // one 8 KB piece (j = 0, 1) of a 16 KB staging unit
+    auto piece_a = [&](int sub, int stage, int kt, int j) {
         const unsigned char* s = sgpr_ptr(abase + (size_t)kt * a_step);
-        dma16(s + oa[sub][0], dma_dst + unit_off(false, sub, stage));
-        dma16(s + oa[sub][1], dma_dst + unit_off(false, sub, stage) + 8192);
+        dma16(s + oa[sub][j], dma_dst + unit_off(false, sub, stage) + j * 8192);
     };
-    auto stage_b = [&](int sub, int stage, int kt) {
+    auto piece_b = [&](int sub, int stage, int kt, int j) {
         const unsigned char* s = sgpr_ptr(bbase + (size_t)kt * b_step);
-        dma16(s + ob[sub][0], dma_dst + unit_off(true, sub, stage));
-        dma16(s + ob[sub][1], dma_dst + unit_off(true, sub, stage) + 8192);
+        dma16(s + ob[sub][j], dma_dst + unit_off(true, sub, stage) + j * 8192);
     };
+    auto stage_a = [&](int sub, int stage, int kt) { piece_a(sub, stage, kt, 0); piece_a(sub, stage, kt, 1); };
+    auto stage_b = [&](int sub, int stage, int kt) { piece_b(sub, stage, kt, 0); piece_b(sub, stage, kt, 1); };
 
     // ---- fragment read bases (per lane)
     uint32_t ra[4], rb[4];
@@ -234,12 +242,23 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
 #define G256_MMA(KS)                                                                                                     \
     acc[mrow * 2 + 0][ncol] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr.template k<KS>(), fa0.template k<KS>(), acc[mrow * 2 + 0][ncol], 0, 0, 0); \
     acc[mrow * 2 + 1][ncol] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr.template k<KS>(), fa1.template k<KS>(), acc[mrow * 2 + 1][ncol], 0, 0, 0);
-    auto mma_quad = [&](int mrow, int ncol, const Frag4<BMM>& bfr) {
+    // d0 / d1: this phase's DMA pieces; issued between the MFMAs (order pinned) as far as ILV says, otherwise by the caller
+    auto mma_quad = [&](int mrow, int ncol, const Frag4<BMM>& bfr, auto&& d0, auto&& d1) {
         __builtin_amdgcn_s_setprio(1);
-        G256_MMA(0) G256_MMA(1) G256_MMA(2) G256_MMA(3)
+        G256_MMA(0)
+        if constexpr (ILV >= 2) { __builtin_amdgcn_sched_barrier(0); d0(); __builtin_amdgcn_sched_barrier(0); }
+        G256_MMA(1) G256_MMA(2)
+        if constexpr (ILV >= 1) { __builtin_amdgcn_sched_barrier(0); d1(); __builtin_amdgcn_sched_barrier(0); }
+        G256_MMA(3)
         __builtin_amdgcn_s_setprio(0);
     };
 #undef G256_MMA
+    // the part of a phase's DMA that stays in front of its first barrier, and the counted wait that goes with it
+    auto pre = [&](auto&& d0, auto&& d1) {
+        if constexpr (ILV < 2) d0();
+        if constexpr (ILV < 1) d1();
+        wait_vm<8 - ILV>();
+    };
     auto bar = [&]() {
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -259,32 +278,44 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
         fa0.template read<unit_off(false, 0, S)>(ra, 0);
         fa1.template read<unit_off(false, 0, S) + (AMM ? 0 : 4096)>(ra, 1);
         fb0.template read<unit_off(true, 0, S) - 65536>(rb, 0);
-        stage_b(1, S ^ 1, t1);
-        wait_vm<8>();
-        bar(); lwait();
-        mma_quad(0, 0, fb0);
-        bar();
+        {
+            auto d0 = [&] { piece_b(1, S ^ 1, t1, 0); };
+            auto d1 = [&] { piece_b(1, S ^ 1, t1, 1); };
+            pre(d0, d1);
+            bar(); lwait();
+            mma_quad(0, 0, fb0, d0, d1);
+            bar();
+        }
         // ---- phase 1: b1
         fb1.template read<unit_off(true, 1, S) - 65536>(rb, 0);
-        stage_a(1, S ^ 1, t1);
-        wait_vm<8>();
-        bar(); lwait();
-        mma_quad(0, 1, fb1);
-        bar();
+        {
+            auto d0 = [&] { piece_a(1, S ^ 1, t1, 0); };
+            auto d1 = [&] { piece_a(1, S ^ 1, t1, 1); };
+            pre(d0, d1);
+            bar(); lwait();
+            mma_quad(0, 1, fb1, d0, d1);
+            bar();
+        }
         // ---- phase 2: a1
         fa0.template read<unit_off(false, 1, S)>(ra, 0);
         fa1.template read<unit_off(false, 1, S) + (AMM ? 0 : 4096)>(ra, 1);
-        stage_a(0, S, t2);
-        wait_vm<8>();
-        bar(); lwait();
-        mma_quad(1, 1, fb1);
-        bar();
+        {
+            auto d0 = [&] { piece_a(0, S, t2, 0); };
+            auto d1 = [&] { piece_a(0, S, t2, 1); };
+            pre(d0, d1);
+            bar(); lwait();
+            mma_quad(1, 1, fb1, d0, d1);
+            bar();
+        }
         // ---- phase 3: nothing new to read
-        stage_b(0, S, t2);
-        wait_vm<8>();
-        bar();
-        mma_quad(1, 0, fb0);
-        bar();
+        {
+            auto d0 = [&] { piece_b(0, S, t2, 0); };
+            auto d1 = [&] { piece_b(0, S, t2, 1); };
+            pre(d0, d1);
+            bar();
+            mma_quad(1, 0, fb0, d0, d1);
+            bar();
+        }
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -359,10 +390,26 @@ static inline int per_split(int ktiles, int nsplit) {
     int per = (ktiles + nsplit - 1) / nsplit;
     return per + (per & 1);
 }
+template <bool AMM, bool BMM, int ILV, class Epi>
+static int launch_ilv(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit, hipStream_t st);
+#ifndef G256_ILV_DEFAULT
+#define G256_ILV_DEFAULT 0
+#endif
 template <bool AMM, bool BMM, class Epi>
 static int launch(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit,
                   hipStream_t st) {
-    auto kern = gemm256_kernel<AMM, BMM, Epi>;
+#ifdef G256_ILV_AB       // experiment build: all three schedules in one library, pa_debug_set(5, 1 + ILV) picks one at run time
+    const int ilv = g_dbg[5] > 0 ? g_dbg[5] - 1 : G256_ILV_DEFAULT;
+    if (ilv == 2) return launch_ilv<AMM, BMM, 2>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
+    if (ilv == 1) return launch_ilv<AMM, BMM, 1>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
+    return launch_ilv<AMM, BMM, 0>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
+#else
+    return launch_ilv<AMM, BMM, G256_ILV_DEFAULT>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
+#endif
+}
+template <bool AMM, bool BMM, int ILV, class Epi>
+static int launch_ilv(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit, hipStream_t st) {
+    auto kern = gemm256_kernel<AMM, BMM, ILV, Epi>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);

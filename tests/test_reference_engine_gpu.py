@@ -1,0 +1,78 @@
+"""The reference's OWN drivers, unmodified, running on the painter_amd modules (SURVEY.md 8b "callers").
+
+`Painter/engine_train.py:train_one_epoch` (with the reference's `util.misc.NativeScalerWithGradNormCount`, `MetricLogger`,
+`util.lr_sched.adjust_learning_rate`, a plain `torch.optim.AdamW`) and `SegGPT_inference/seggpt_engine.py:run_one_image` are imported
+from a reference checkout through oracle/ref_import.py (stand-ins only for the absent third-party modules) and handed OUR modules.
+
+Needs BOTH an MI355X and the reference tree (PAINTER_REFERENCE_ROOT, default /root/reference): the GPU boxes of this project have no
+reference tree and the build container has no GPU, so here the run itself is skipped -- the first machine that has both executes it.
+What CAN be checked without a GPU is checked in tests/test_reference_import_cpu.py: the unmodified drivers import through the stubs
+and every attribute of the model they touch exists on our classes."""
+import types
+
+import pytest
+import torch
+
+from oracle import painter_oracle as O
+from oracle import ref_import
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not ref_import.reference_available(), reason="no reference checkout (PAINTER_REFERENCE_ROOT)"),
+              pytest.mark.skipif(not torch.cuda.is_available(), reason="needs an MI355X")]
+
+
+def _small(cls, cfg, **kw):
+    from functools import partial
+    import torch.nn as nn
+    return cls(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+               drop_path_rate=0.1, window_size=14, qkv_bias=True, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
+               window_block_indexes=([0, 1], [3, 4]), residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat",
+               decoder_embed_dim=cfg.decoder_embed_dim, loss_func="smoothl1", **kw)
+
+
+def test_reference_train_one_epoch_drives_the_hip_module():
+    """engine_train.train_one_epoch (Painter/engine_train.py:34-144), unmodified: fp16 autocast context, GradScaler through the
+    reference's NativeScalerWithGradNormCount, accum_iter 2, clip 3.0, lr schedule, MetricLogger -- four iterations on the small
+    config; the loss must be finite, the parameters must move, and the averaged stats must come back."""
+    from painter_amd import models_painter
+    eng = ref_import.load_reference_engine_train()
+    cfg = O.small_config()
+    model = _small(models_painter.Painter, cfg, compute_dtype="bf16").cuda()
+    model.load_state_dict(O.random_params(cfg, 3))
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    batches = []
+    for k in range(4):
+        imgs, tgts, mask, valid = O.synthetic_batch(cfg, 2, 100 + k, "random")
+        batches.append((imgs, tgts, mask.reshape(2, *cfg.grid), valid))
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.05)
+    args = types.SimpleNamespace(accum_iter=2, clip_grad=3.0, lr=1e-3, min_lr=1e-5, warmup_epochs=1, epochs=2, log_wandb=False)
+    stats = eng.train_one_epoch(model, batches, opt, torch.device("cuda"), 0, eng.misc.NativeScalerWithGradNormCount(),
+                                log_writer=None, global_rank=0, args=args)
+    assert set(stats) >= {"loss", "lr", "loss_scale", "grad_norm"} and torch.isfinite(torch.tensor(stats["loss"]))
+    moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in model.named_parameters())
+    assert moved > 0.9 * len(before), moved
+
+
+def test_reference_run_one_image_drives_the_hip_seggpt_module():
+    """seggpt_engine.run_one_image (SegGPT_inference/seggpt_engine.py:26-53), unmodified, on our SegGPT module: two prompts over one
+    query (feature ensemble on), float64 host arrays in, a de-normalised [H/2, W, 3] picture out; checked against the CPU oracle."""
+    import numpy as np
+    from painter_amd import models_seggpt
+    eng = ref_import.load_reference_seggpt_engine()
+    cfg = O.small_config(seggpt=True)
+    model = _small(models_seggpt.SegGPT, cfg, compute_dtype="fp32").cuda().eval()
+    P = O.random_params(cfg, 5)
+    model.load_state_dict(P)
+    model.seg_type = "instance"
+    imgs, tgts, _, _ = O.synthetic_batch(cfg, 2, 9, "half")
+    img = imgs.permute(0, 2, 3, 1).double().numpy()
+    tgt = tgts.permute(0, 2, 3, 1).double().numpy()
+    out = eng.run_one_image(img, tgt, model, torch.device("cuda"))
+    L = cfg.grid[0] * cfg.grid[1]
+    mask = torch.zeros(1, L)
+    mask[:, L // 2:] = 1
+    with torch.no_grad():
+        _, yo, _ = O.forward(P, cfg, imgs, tgts, mask, torch.ones_like(tgts), torch.ones(2, 1), 0)
+    y = O.unpatchify(yo, cfg.patch_size).permute(0, 2, 3, 1)
+    ref = torch.clip((y[0, y.shape[1] // 2:] * torch.tensor(O.IMAGENET_STD) + torch.tensor(O.IMAGENET_MEAN)) * 255, 0, 255)
+    assert out.shape == ref.shape and float((out - ref).abs().max()) < 0.05

@@ -19,6 +19,7 @@ for s in "$@"; do
     pmc)       (cd /tmp && for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
                   n=$(echo $c | cut -d' ' -f1); PAINTER_AMD_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/gpurun_out/pmc_$n -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/pmc_$n.log 2>&1; done); echo "pmc done" ;;
     overlap)   PAINTER_AMD_DDP_SELFTEST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 timeout 600 python tools/gradsync_overlap.py > gpurun_out/overlap.log 2>&1; echo "overlap rc=$?"; tail -12 gpurun_out/overlap.log ;;
+    ilv)       PAINTER_AMD_LIB=painter_amd/lib/libpainter_hip_ilv.so timeout 900 python tools/gemm_ilv_ab.py step > gpurun_out/ilv.log 2>&1; echo "ilv rc=$?"; tail -40 gpurun_out/ilv.log ;;
     *)         echo "unknown section $s" ;;
   esac
 done

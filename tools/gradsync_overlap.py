@@ -31,7 +31,7 @@ class StandIn:
         self.scratch = None
         self.events = []
 
-    def ready(self, G, names):
+    def ready(self, G, names, flat=None):
         cur = torch.cuda.current_stream()
         self.stream.wait_stream(cur)
         n = sum(G[k].numel() for k in names)
