@@ -134,10 +134,13 @@ int64_t pa_patch_embed_wgrad_workspace_bytes(int D, int P);
 int pa_patch_embed_wgrad(int dtype, const void* dpe /*T [2BL, D]*/, const float* imgs, const float* tgts,
                          float* dw /*f32 [D, 3*P*P]*/, void* workspace, int batch, int Hp, int Wp, int P, int D,
                          hipStream_t stream);
-/* get_abs_pos (util/vitdet_utils.py:128-157) as the constant bicubic operator M [L, S] (host-built, f32);
- * pe/dpe point at pos_embed[0, skip_cls:, :] ([S, D]). */
-int pa_pos_fwd(const float* M, const float* pe, float* pos, int L, int S, int D, hipStream_t stream);
-int pa_pos_bwd(const float* M, const float* gx, const float* gy, float* dpe, int L, int S, int D, hipStream_t stream);
+/* get_abs_pos (util/vitdet_utils.py:128-157) as the constant bicubic operator M [L, S] (host-built), in row-sparse form
+ * (painter_amd/hostmath.py sparse_rows: int32 column indices + f32 values, K entries per row, zero-padded): pos = M . pe with
+ * (idx, val, K) of M; dpe = M^T . (gx + gy) with those of M^T.  pe/dpe point at pos_embed[0, skip_cls:, :] ([S, D]). */
+int pa_pos_fwd(const int* idx /*[L, K]*/, const float* val /*[L, K]*/, int K, const float* pe /*[S, D]*/, float* pos /*[L, D]*/, int L, int D,
+               hipStream_t stream);
+int pa_pos_bwd(const int* idxT /*[S, KT]*/, const float* valT /*[S, KT]*/, int KT, const float* gx /*[L, D]*/, const float* gy /*[L, D]*/,
+               float* dpe /*[S, D]*/, int S, int D, hipStream_t stream);
 /* backward of the token assembly: dpe T [2BL, D]; sums f32 [3, L, D] = sum_b dx | sum_b dy | sum_b w*dy */
 int pa_tokens_bwd(int dtype, const float* dx0, const unsigned char* mask, int mask_batch_stride, void* dpe, float* sums,
                   int batch, int L, int D, hipStream_t stream);

@@ -23,41 +23,36 @@ extern "C" int pa_cast_bf16(const float* in, void* out, int64_t n, hipStream_t s
 }
 
 // ------------------------------------------------------------------------------- abs pos: pos = M . pos_embed[0, skip:]
-// get_abs_pos (util/vitdet_utils.py:128-157) as the constant bicubic operator M [L, S].
-__global__ void pos_fwd_kernel(const float* __restrict__ M, const float* __restrict__ pe, float* __restrict__ pos, int L, int S, int D) {
-    const int l = blockIdx.y, n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= D) return;
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) {
-        const float m = M[(size_t)l * S + s];
-        if (m != 0.f) acc = fmaf(m, pe[(size_t)s * D + n], acc);
-    }
-    pos[(size_t)l * D + n] = acc;
-}
-// block = 64 columns x 4 row-lanes: the token loop (most of M is zero: bicubic support is 4x4 source cells) is split 4 ways and the
-// partial sums are combined through LDS in a fixed order
-__global__ __launch_bounds__(256) void pos_bwd_kernel(const float* __restrict__ M, const float* __restrict__ g0, const float* __restrict__ g1,
-                                                      float* __restrict__ dpe, int L, int S, int D) {
+// get_abs_pos (util/vitdet_utils.py:128-157) as the constant bicubic operator M [L, S], applied in its
+// row-sparse form (hostmath.sparse_rows): out[r][n] = sum_j val[r][j] * (x0[idx[r][j]][n] + x1[idx[r][j]][n]), K entries per row
+// (padding entries have val 0).  Forward: rows = tokens, 16 entries each; backward (M^T): rows = source cells.  The dense form cost
+// 67 / 266 us per step (a dependent load of M per (token, source) pair); this one streams K short rows.
+// block = 64 columns x 4 entry-lanes; partial sums are combined through LDS in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void sparse_rows_kernel(const int* __restrict__ idx, const float* __restrict__ val, int K, const float* __restrict__ x0,
+                                                          const float* __restrict__ x1, float* __restrict__ out, int D) {
     __shared__ float red[4][64];
-    const int s = blockIdx.y, cl = threadIdx.x & 63, rl = threadIdx.x >> 6, n = blockIdx.x * 64 + cl;
+    const int r = blockIdx.y, cl = threadIdx.x & 63, jl = threadIdx.x >> 6, n = blockIdx.x * 64 + cl;
     float acc = 0.f;
     if (n < D) {
-        for (int l = rl; l < L; l += 4) {
-            const float m = M[(size_t)l * S + s];
-            if (m != 0.f) acc = fmaf(m, g0[(size_t)l * D + n] + g1[(size_t)l * D + n], acc);
+        for (int j = jl; j < K; j += 4) {
+            const float m = val[(size_t)r * K + j];
+            const size_t o = (size_t)idx[(size_t)r * K + j] * D + n;
+            acc = fmaf(m, x1 ? x0[o] + x1[o] : x0[o], acc);
         }
     }
-    red[rl][cl] = acc;
+    red[jl][cl] = acc;
     __syncthreads();
-    if (rl == 0 && n < D) dpe[(size_t)s * D + n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+    if (jl == 0 && n < D) out[(size_t)r * D + n] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
-// pe / dpe point at the first non-cls row of pos_embed ([S, D])
-extern "C" int pa_pos_fwd(const float* M, const float* pe, float* pos, int L, int S, int D, hipStream_t st) {
-    PA_LAUNCH(pos_fwd_kernel, dim3((D + 255) / 256, L), dim3(256), 0, st, M, pe, pos, L, S, D);
+// pe / dpe point at the first non-cls row of pos_embed ([S, D]); (idx, val, K) = sparse_rows(M) for the forward, sparse_rows(M^T) for the backward
+extern "C" int pa_pos_fwd(const int* idx, const float* val, int K, const float* pe, float* pos, int L, int D, hipStream_t st) {
+    if (K < 1) return (int)hipErrorInvalidValue;
+    PA_LAUNCH(sparse_rows_kernel, dim3((D + 63) / 64, L), dim3(256), 0, st, idx, val, K, pe, (const float*)nullptr, pos, D);
     LAUNCH_CHECK();
 }
-extern "C" int pa_pos_bwd(const float* M, const float* gx, const float* gy, float* dpe, int L, int S, int D, hipStream_t st) {
-    PA_LAUNCH(pos_bwd_kernel, dim3((D + 63) / 64, S), dim3(256), 0, st, M, gx, gy, dpe, L, S, D);
+extern "C" int pa_pos_bwd(const int* idxT, const float* valT, int KT, const float* gx, const float* gy, float* dpe, int S, int D, hipStream_t st) {
+    if (KT < 1) return (int)hipErrorInvalidValue;
+    PA_LAUNCH(sparse_rows_kernel, dim3((D + 63) / 64, S), dim3(256), 0, st, idxT, valT, KT, gx, gy, dpe, D);
     LAUNCH_CHECK();
 }
 

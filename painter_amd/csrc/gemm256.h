@@ -19,6 +19,7 @@
 // the first barrier of phase p and read in phase p+1 or later; a unit is re-staged >= 2 phases after its last ds_read.
 #pragma once
 #include "common.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace g256 {
@@ -399,7 +400,8 @@ template <bool AMM, bool BMM, class Epi>
 static int launch(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit,
                   hipStream_t st) {
 #ifdef G256_ILV_AB       // experiment build: all three schedules in one library, pa_debug_set(5, 1 + ILV) picks one at run time
-    const int ilv = g_dbg[5] > 0 ? g_dbg[5] - 1 : G256_ILV_DEFAULT;
+    static const int env_ilv = [] { const char* v = getenv("PA_G256_ILV"); return v ? atoi(v) : G256_ILV_DEFAULT; }();
+    const int ilv = g_dbg[5] > 0 ? g_dbg[5] - 1 : env_ilv;
     if (ilv == 2) return launch_ilv<AMM, BMM, 2>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
     if (ilv == 1) return launch_ilv<AMM, BMM, 1>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
     return launch_ilv<AMM, BMM, 0>(A, lda, B, ldb, epi, M, N, K, nsplit, st);

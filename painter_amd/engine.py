@@ -121,9 +121,13 @@ class HotPath:
 
     # ------------------------------------------------------------------ constants / casts
     def pos_operator(self, device):
-        if self._M is None or self._M.device != device:
+        """-> (sparse rows of M, sparse rows of M^T) on the device: the constant bicubic resize of the pre-training position grid."""
+        if self._M is None or self._M[0][0].device != device:
             c = self.cfg
-            self._M = torch.from_numpy(hostmath.abs_pos_operator(c.src, c.Hp, c.Wp)).to(device)
+            M = hostmath.abs_pos_operator(c.src, c.Hp, c.Wp)
+            fwd, bwd = hostmath.sparse_rows(M), hostmath.sparse_rows(M.T)
+            dev = lambda t: (torch.from_numpy(t[0]).to(device), torch.from_numpy(t[1]).to(device))
+            self._M = (dev(fwd), dev(bwd))
         return self._M
 
     def w(self, name, P):
@@ -191,9 +195,8 @@ class HotPath:
         S.B, S.need_grad = B, need_grad
         S.imgs, S.tgts, S.mask, S.valid = imgs, tgts, mask_u8, valid
         S.drop = drop_scales
-        M = self.pos_operator(dev)
         pe = P["pos_embed"][0, c.cls:]
-        pos = ops.pos_fwd(M, pe, L, c.src * c.src, D)
+        pos = ops.pos_fwd(self.pos_operator(dev)[0], pe, L, D)
         x = ops.patch_embed_fwd(T, imgs, tgts, self.w_patch(P), P["patch_embed.proj.bias"],
                                 P["mask_token"], P["segment_token_x"], P["segment_token_y"], pos, mask_u8,
                                 P.get("type_token_cls") if c.seggpt else None, P.get("type_token_ins") if c.seggpt else None,
@@ -421,7 +424,7 @@ class HotPath:
         G["patch_embed.proj.weight"] = ops.patch_embed_wgrad(dpe, S.imgs, S.tgts, B, c.Hp, c.Wp, c.P, D).view(D, 3, c.P, c.P)
         G["patch_embed.proj.bias"] = ops.colsum(dpe)
         dposemb = torch.zeros_like(P["pos_embed"])
-        ops.pos_bwd(self.pos_operator(dev), sums[0], sums[1], dposemb[0, c.cls:], L, c.src * c.src, D)
+        ops.pos_bwd(self.pos_operator(dev)[1], sums[0], sums[1], dposemb[0, c.cls:], c.src * c.src, D)
         G["pos_embed"] = dposemb
         G["segment_token_x"] = ops.colsum(sums[0]).view(1, 1, 1, D)
         G["segment_token_y"] = ops.colsum(sums[1]).view(1, 1, 1, D)

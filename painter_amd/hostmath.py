@@ -38,6 +38,22 @@ def abs_pos_operator(src, h, w):
     return m.astype(np.float32)
 
 
+def sparse_rows(m):
+    """Row-wise sparse form of a dense operator m [R, C]: (idx int32 [R, K], val float32 [R, K], K) with K = the largest number of
+    non-zeros in a row; rows with fewer are padded with (0, 0.0).  The bicubic resize operator has 16 non-zeros per output token and
+    (transposed) <= a few hundred per source cell, out of 196 / 1568 columns."""
+    m = np.asarray(m)
+    nz = m != 0
+    K = max(1, int(nz.sum(1).max()))
+    idx = np.zeros((m.shape[0], K), dtype=np.int32)
+    val = np.zeros((m.shape[0], K), dtype=np.float32)
+    for r in range(m.shape[0]):
+        c = np.nonzero(nz[r])[0]
+        idx[r, :len(c)] = c
+        val[r, :len(c)] = m[r, c]
+    return idx, val, K
+
+
 def drop_path_rates(drop_path_rate, depth):
     """torch.linspace(0, drop_path_rate, depth) (models_painter.py:293) in float32 semantics."""
     if depth == 1:

@@ -221,14 +221,20 @@ def cast_bf16(x, out=None):
     return out
 
 
-def pos_fwd(M, pe, L, S, D):
+def pos_fwd(op, pe, L, D):
+    """op = (idx int32 [L, K], val f32 [L, K]) device tensors of hostmath.sparse_rows(M); pe f32 [S, D] -> pos f32 [L, D] = M . pe."""
+    idx, val = op
+    assert idx.dtype == torch.int32 and val.dtype == torch.float32 and idx.shape == val.shape == (L, idx.shape[1])
     pos = torch.empty((L, D), dtype=torch.float32, device=pe.device)
-    check(lib.pa_pos_fwd(p(M), p(pe), p(pos), L, S, D, stream()), "pa_pos_fwd")
+    check(lib.pa_pos_fwd(p(idx), p(val), idx.shape[1], p(pe), p(pos), L, D, stream()), "pa_pos_fwd")
     return pos
 
 
-def pos_bwd(M, gx, gy, dpe, L, S, D):
-    check(lib.pa_pos_bwd(p(M), p(gx), p(gy), p(dpe), L, S, D, stream()), "pa_pos_bwd")
+def pos_bwd(opT, gx, gy, dpe, S, D):
+    """opT = sparse_rows(M^T) on the device; dpe f32 [S, D] <- M^T . (gx + gy)."""
+    idx, val = opT
+    assert idx.dtype == torch.int32 and val.dtype == torch.float32 and idx.shape == val.shape == (S, idx.shape[1])
+    check(lib.pa_pos_bwd(p(idx), p(val), idx.shape[1], p(gx), p(gy), p(dpe), S, D, stream()), "pa_pos_bwd")
 
 
 def patch_weight_pack(w, T, P, out=None):

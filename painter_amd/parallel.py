@@ -69,11 +69,15 @@ class GradSync:
             else:
                 small.append(n)
         if small and flat is not None:
+            # the tensors that are views of `flat` travel inside it; anything else that is small here (the weight matrices of a
+            # down-sized test model, say) takes the flattening path below
             lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * flat.element_size()
-            assert all(lo <= G[n].data_ptr() and G[n].data_ptr() + G[n].numel() * 4 <= hi for n in small), "flat does not hold every small gradient"
+            inside = [n for n in small if lo <= G[n].data_ptr() and G[n].data_ptr() + G[n].numel() * G[n].element_size() <= hi]
+            assert inside, "flat holds none of the bucket's gradients"
             work, post = self._reduce(flat)
             self._pending.append((work, flat, post))
-        elif small:
+            small = [n for n in small if n not in inside]
+        if small:
             ts = [G[n] for n in small]
             flat = torch.cat([t.reshape(-1) for t in ts])
             work, post = self._reduce(flat)

@@ -152,3 +152,17 @@ def test_fused_adamw_takes_the_references_layer_decay_groups_and_lr_schedule():
         assert (id(p) in nd) == (p.ndim == 1 or n in ("pos_embed", "cls_token")), n
     sd = opt.state_dict()
     assert len(sd["param_groups"]) == 52
+
+
+def test_sparse_rows_is_a_lossless_form_of_the_position_operator():
+    import numpy as np
+    for src, h, w in ((14, 56, 28), (16, 64, 32), (14, 8, 4)):
+        m = hostmath.abs_pos_operator(src, h, w)
+        for mat in (m, m.T):
+            idx, val, K = hostmath.sparse_rows(mat)
+            assert idx.dtype == np.int32 and val.dtype == np.float32 and idx.shape == val.shape == (mat.shape[0], K)
+            back = np.zeros_like(mat)
+            for r in range(mat.shape[0]):
+                np.add.at(back[r], idx[r], val[r])
+            assert np.array_equal(back, mat)
+        assert hostmath.sparse_rows(m)[2] <= 16                      # 4 x 4 bicubic taps per output token

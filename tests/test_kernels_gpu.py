@@ -613,6 +613,29 @@ def test_patch_embed_and_token_assembly_in_isolation(T, seggpt, P):
     assert relerr(dw, refw) < (2e-6 if T == torch.float32 else 2e-5), relerr(dw, refw)
 
 
+@pytest.mark.parametrize("src,Hp,Wp", [(14, 56, 28), (16, 64, 32), (14, 8, 4), (14, 14, 14)])
+def test_abs_pos_resize_operator_sparse_rows_fwd_bwd(src, Hp, Wp):
+    """pa_pos_fwd / pa_pos_bwd (get_abs_pos, util/vitdet_utils.py:128-157, as the constant operator M in row-sparse form) against
+    F.interpolate(bicubic, align_corners=False) itself and its autograd, in fp64."""
+    from painter_amd import hostmath
+    D, L, S = 96, Hp * Wp, src * src
+    M = hostmath.abs_pos_operator(src, Hp, Wp)
+    dev = lambda t: (torch.from_numpy(t[0]).to(DEV), torch.from_numpy(t[1]).to(DEV))
+    fwd, bwd = dev(hostmath.sparse_rows(M)), dev(hostmath.sparse_rows(M.T))
+    pe = gen((S, D), 1)
+    pos = ops.pos_fwd(fwd, pe, L, D)
+    pe64 = pe.double().cpu().clone().requires_grad_(True)
+    ref = torch.nn.functional.interpolate(pe64.reshape(1, src, src, D).permute(0, 3, 1, 2), size=(Hp, Wp), mode="bicubic", align_corners=False) \
+        if (Hp, Wp) != (src, src) else pe64.reshape(1, src, src, D).permute(0, 3, 1, 2)
+    ref = ref.permute(0, 2, 3, 1).reshape(L, D)
+    assert relerr(pos, ref.detach()) < 2e-6
+    gx, gy = gen((L, D), 2), gen((L, D), 3)
+    dpe = torch.empty((S, D), device=DEV)
+    ops.pos_bwd(bwd, gx, gy, dpe, S, D)
+    ref.backward((gx + gy).double().cpu())
+    assert relerr(dpe, pe64.grad) < 2e-6
+
+
 def test_c_abi_of_the_hot_path_rejects_bad_shapes_instead_of_reading_out_of_bounds():
     """Error behaviour at the boundary: every entry point returns a hipError (the Python binding raises) for a shape its kernels cannot
     take -- contraction not a multiple of the vector width, token count that is not Hp x Wp, feature width not a multiple of 4, odd debug

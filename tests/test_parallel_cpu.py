@@ -61,17 +61,21 @@ def _worker(rank, world, port, q):
     g2 = torch.Generator().manual_seed(500 + rank)
     flat = torch.randn(7 + 20, generator=g2)
     big = torch.randn(16, 8, generator=g2)
-    G2 = {"blocks.3.mlp.fc1.bias": flat[:7], "blocks.3.attn.rel_pos_h": flat[7:].view(5, 4), "blocks.3.mlp.fc1.weight": big}
+    stray = torch.randn(6, 4, generator=g2)          # a small tensor that is NOT a view of flat (a down-sized model's weight matrix): flattening path
+    G2 = {"blocks.3.mlp.fc1.bias": flat[:7], "blocks.3.attn.rel_pos_h": flat[7:].view(5, 4), "blocks.3.mlp.fc1.weight": big,
+          "blocks.3.attn.proj.weight": stray}
     ptrs = {n: t.data_ptr() for n, t in G2.items()}
     sync.ready(G2, list(G2), flat=flat)
     sync.finish()
-    ref_flat, ref_big = torch.zeros(27), torch.zeros(16, 8)
+    ref_flat, ref_big, ref_stray = torch.zeros(27), torch.zeros(16, 8), torch.zeros(6, 4)
     for rk in range(world):
         gg = torch.Generator().manual_seed(500 + rk)
         ref_flat += torch.randn(27, generator=gg)
         ref_big += torch.randn(16, 8, generator=gg)
+        ref_stray += torch.randn(6, 4, generator=gg)
     ok &= bool(torch.allclose(flat, ref_flat / world, atol=1e-6)) and bool(torch.allclose(big, ref_big / world, atol=1e-6))
-    ok &= all(G2[n].data_ptr() == ptrs[n] for n in G2)          # still the same views: nothing was copied or re-pointed
+    ok &= bool(torch.allclose(G2["blocks.3.attn.proj.weight"], ref_stray / world, atol=1e-6))
+    ok &= all(G2[n].data_ptr() == ptrs[n] for n in G2 if n != "blocks.3.attn.proj.weight")   # still the same views: nothing was copied or re-pointed
     try:
         sync.ready({"a": torch.zeros(3)}, ["a"], flat=torch.zeros(3))
         ok = False                                               # a flat buffer that does not hold the gradient must be refused

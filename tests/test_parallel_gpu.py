@@ -99,9 +99,17 @@ def test_two_ranks_on_one_gpu_average_the_hip_models_gradients(wrapper):
     for p in procs:
         p.start()
     res = {}
-    for _ in range(world):
-        rank, same, digest, worst = q.get(timeout=600)
-        res[rank] = (same, digest, worst)
+    import queue
+    import time
+    deadline = time.time() + 420
+    while len(res) < world:
+        try:
+            rank, same, digest, worst = q.get(timeout=5)
+            res[rank] = (same, digest, worst)
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, "a rank died (exit codes %s): see its traceback above" % dead      # fail in seconds, not after the full timeout
+            assert time.time() < deadline, "ranks did not finish in time"
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

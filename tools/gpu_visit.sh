@@ -20,6 +20,9 @@ for s in "$@"; do
                   n=$(echo $c | cut -d' ' -f1); PAINTER_AMD_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/gpurun_out/pmc_$n -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/pmc_$n.log 2>&1; done); echo "pmc done" ;;
     overlap)   PAINTER_AMD_DDP_SELFTEST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 timeout 600 python tools/gradsync_overlap.py > gpurun_out/overlap.log 2>&1; echo "overlap rc=$?"; tail -12 gpurun_out/overlap.log ;;
     ilv)       PAINTER_AMD_LIB=painter_amd/lib/libpainter_hip_ilv.so timeout 900 python tools/gemm_ilv_ab.py step > gpurun_out/ilv.log 2>&1; echo "ilv rc=$?"; tail -40 gpurun_out/ilv.log ;;
+    power)     PAINTER_AMD_LIB=painter_amd/lib/libpainter_hip_ilv.so timeout 600 python tools/power_probe.py > gpurun_out/power.log 2>&1; echo "power rc=$?"; tail -12 gpurun_out/power.log ;;
+    ilvprof)   (cd /tmp && for i in 0 2; do PA_G256_ILV=$i PAINTER_AMD_LIB=$OLDPWD/painter_amd/lib/libpainter_hip_ilv.so PAINTER_AMD_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_ilv$i -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_ilv$i.log 2>&1; done); echo "ilvprof done"; ls gpurun_out/prof_ilv0 gpurun_out/prof_ilv2 | head ;;
+    fixtests)  timeout 600 python -m pytest tests/test_parallel_gpu.py tests/test_kernels_gpu.py -m gpu -q -x -k "two_ranks or abs_pos or generations" > gpurun_out/fixtests.log 2>&1; echo "fixtests rc=$?"; tail -5 gpurun_out/fixtests.log ;;
     *)         echo "unknown section $s" ;;
   esac
 done
