@@ -9,8 +9,8 @@
 // transposing read ds_read_b64_tr_b16, so no transposed copy of an activation or a weight ever exists in HBM.
 //
 // Schedule (per contraction tile: 4 phases = the 4 quadrants of the wave's 128 x 64 tile):
-//     phase = { ds_read this quadrant's new fragments | issue one 16 KB staging unit (2 LDS-DMA per lane) |
-//               s_waitcnt vmcnt(8) } barrier { 8 MFMA } barrier
+//     phase = { ds_read this quadrant's new fragments | s_waitcnt vmcnt(6) } barrier
+//             { 8 MFMA with the two LDS-DMA pieces of one 16 KB staging unit issued between them (ILV = 2, below) } barrier
 // The two wave rows run half a phase apart (the lower row takes one extra barrier on entry), so on every SIMD one wave
 // feeds the matrix pipe while its partner issues LDS reads and DMA.  LDS holds 8 staging units (2 stages x {a0,a1,b0,b1},
 // a unit = the rows every wave needs in the same phase); a unit is re-staged two phases after its last read and read five
@@ -394,8 +394,8 @@ static inline int per_split(int ktiles, int nsplit) {
 template <bool AMM, bool BMM, int ILV, class Epi>
 static int launch_ilv(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit, hipStream_t st);
 #ifndef G256_ILV_DEFAULT
-#define G256_ILV_DEFAULT 0
-#endif
+#define G256_ILV_DEFAULT 2     // round 3 (tools/gemm_ilv_ab.py, MI355X): 2 is 4-15 % faster than 0 on the forward GEMMs, 4-6 % on the data gradients,
+#endif                         // 2 % on the weight gradients, bit-identical results; 1 = 0.  In the training step the gain shrinks to ~1 % (DVFS)
 template <bool AMM, bool BMM, class Epi>
 static int launch(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit,
                   hipStream_t st) {

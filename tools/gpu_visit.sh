@@ -14,14 +14,14 @@ for s in "$@"; do
     bench)     timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-600 gpurun_out/bench.json ;;
     benchfast) timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-optimizer > gpurun_out/benchfast.json 2> gpurun_out/benchfast.err; echo "benchfast rc=$?"; cut -c1-400 gpurun_out/benchfast.json ;;
     huge)      timeout 900 python bench.py --model vit_huge --steps 5 --warmup 2 --no-cpu-baseline --min-seconds 2 > gpurun_out/bench_huge.json 2> gpurun_out/bench_huge.err; echo "huge rc=$?"; cut -c1-600 gpurun_out/bench_huge.json; tail -3 gpurun_out/bench_huge.err ;;
-    profile)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_two_stream -o two -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_two.log 2>&1
-                PAINTER_AMD_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_one_stream -o one -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_one.log 2>&1); echo "profile done"; ls gpurun_out/prof_one_stream gpurun_out/prof_two_stream 2>/dev/null | head ;;
+    profile)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_two_stream -o two -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_two.log 2>&1
+                PAINTER_AMD_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_one_stream -o one -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_one.log 2>&1); echo "profile done"; ls gpurun_out/prof_one_stream gpurun_out/prof_two_stream 2>/dev/null | head ;;
     pmc)       (cd /tmp && for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
-                  n=$(echo $c | cut -d' ' -f1); PAINTER_AMD_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --pmc $c -d $OLDPWD/gpurun_out/pmc_$n -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/pmc_$n.log 2>&1; done); echo "pmc done" ;;
+                  n=$(echo $c | cut -d' ' -f1); PAINTER_AMD_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OLDPWD/gpurun_out/pmc_$n -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/pmc_$n.log 2>&1; done); echo "pmc done" ;;
     overlap)   PAINTER_AMD_DDP_SELFTEST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 timeout 600 python tools/gradsync_overlap.py > gpurun_out/overlap.log 2>&1; echo "overlap rc=$?"; tail -12 gpurun_out/overlap.log ;;
     ilv)       PAINTER_AMD_LIB=painter_amd/lib/libpainter_hip_ilv.so timeout 900 python tools/gemm_ilv_ab.py step > gpurun_out/ilv.log 2>&1; echo "ilv rc=$?"; tail -40 gpurun_out/ilv.log ;;
     power)     PAINTER_AMD_LIB=painter_amd/lib/libpainter_hip_ilv.so timeout 600 python tools/power_probe.py > gpurun_out/power.log 2>&1; echo "power rc=$?"; tail -12 gpurun_out/power.log ;;
-    ilvprof)   (cd /tmp && for i in 0 2; do PA_G256_ILV=$i PAINTER_AMD_LIB=$OLDPWD/painter_amd/lib/libpainter_hip_ilv.so PAINTER_AMD_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats -d $OLDPWD/gpurun_out/prof_ilv$i -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_ilv$i.log 2>&1; done); echo "ilvprof done"; ls gpurun_out/prof_ilv0 gpurun_out/prof_ilv2 | head ;;
+    ilvprof)   (cd /tmp && for i in 0 2; do PA_G256_ILV=$i PAINTER_AMD_LIB=$OLDPWD/painter_amd/lib/libpainter_hip_ilv.so PAINTER_AMD_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_ilv$i -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_ilv$i.log 2>&1; done); echo "ilvprof done"; ls gpurun_out/prof_ilv0 gpurun_out/prof_ilv2 | head ;;
     fixtests)  timeout 600 python -m pytest tests/test_parallel_gpu.py tests/test_kernels_gpu.py -m gpu -q -x -k "two_ranks or abs_pos or generations" > gpurun_out/fixtests.log 2>&1; echo "fixtests rc=$?"; tail -5 gpurun_out/fixtests.log ;;
     *)         echo "unknown section $s" ;;
   esac

@@ -30,46 +30,32 @@ def _read(path):
         return None
 
 
-class Sampler(threading.Thread):
-    def __init__(self):
-        super().__init__(daemon=True)
-        self.power_files = [f for f in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average") + glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")]
-        self.freq_files = glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/freq1_input")
-        self.cap_files = glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_cap")
-        self.samples, self.run, self.on = [], True, False
-        self.use_smi = not self.power_files
+class Sampler:
+    """Samples every amdgpu hwmon node (a box may expose the nodes of GPUs that are not ours): the card whose power moves with the load
+    is the one the process runs on; it is picked after the first loaded measurement."""
 
-    def smi(self):
-        try:
-            out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=5).stdout
-            import json
-            d = json.loads(out)
-            card = next(iter(d.values()))
-            pw = next((float(v) for k, v in card.items() if "ower" in k and "(W)" in k), None)
-            ck = next((v for k, v in card.items() if "sclk" in k and "clock speed" in k), None)
-            mhz = float(ck.strip("()Mhz")) if ck else None
-            return pw, mhz
-        except Exception:
-            return None, None
+    def __init__(self):
+        self.nodes = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        self.pfile = {n: next((os.path.join(n, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(n, f))), None) for n in self.nodes}
+        self.ffile = {n: os.path.join(n, "freq1_input") for n in self.nodes}
+        self.cap = {n: _read(os.path.join(n, "power1_cap")) for n in self.nodes}
+        self.samples, self.alive, self.on, self.card = [], True, False, None
 
     def once(self):
-        if self.use_smi:
-            return self.smi()
-        pw = _read(self.power_files[0])
-        fq = _read(self.freq_files[0]) if self.freq_files else None
-        return (float(pw) / 1e6 if pw else None, float(fq) / 1e6 if fq else None)
+        out = {}
+        for n in self.nodes:
+            pw, fq = _read(self.pfile[n]) if self.pfile[n] else None, _read(self.ffile[n])
+            out[n] = (float(pw) / 1e6 if pw else None, float(fq) / 1e6 if fq else None)
+        return out
 
-    def run_(self):
-        while self.run:
+    def loop(self):
+        while self.alive:
             if self.on:
                 self.samples.append(self.once())
-            time.sleep(0.5 if self.use_smi else 0.1)
-
-    run = True
+            time.sleep(0.1)
 
     def start(self):
-        self._t = threading.Thread(target=self.run_, daemon=True)
-        self._t.start()
+        threading.Thread(target=self.loop, daemon=True).start()
 
     def measure(self, fn, seconds, unit_work):
         fn()
@@ -83,16 +69,18 @@ class Sampler(threading.Thread):
             n += 4
         dt = time.time() - t0
         self.on = False
-        pw = [p for p, _ in self.samples if p is not None]
-        ck = [c for _, c in self.samples if c is not None]
-        return {"rate": n * unit_work / dt, "ms": dt / n * 1e3, "power_mean": statistics.mean(pw) if pw else None, "power_max": max(pw) if pw else None,
-                "sclk_mean": statistics.mean(ck) if ck else None, "n": len(self.samples)}
+        per = {}
+        for node in self.nodes:
+            pw = [s_[node][0] for s_ in self.samples if s_[node][0] is not None]
+            ck = [s_[node][1] for s_ in self.samples if s_[node][1] is not None]
+            per[node] = (statistics.mean(pw) if pw else 0.0, max(pw) if pw else 0.0, statistics.mean(ck) if ck else 0.0, min(ck) if ck else 0.0)
+        return {"rate": n * unit_work / dt, "ms": dt / n * 1e3, "per": per, "n": len(self.samples)}
 
 
 def main():
     dev = torch.device("cuda")
     s = Sampler()
-    print("power files", s.power_files, "freq files", s.freq_files, "cap", [(_read(f)) for f in s.cap_files], "rocm-smi fallback", s.use_smi, flush=True)
+    print("hwmon nodes:", len(s.nodes), "power caps (uW):", sorted(set(s.cap.values())), flush=True)
     s.start()
     m = models_painter.painter_vit_large_patch16_input896x448(compute_dtype="bf16")
     bench.randomize_parameters(m, seed=1)
@@ -141,13 +129,21 @@ def main():
         work.append(("gemm fc1+gelu" + ("" if i is None else " ILV%d" % i), f, 2.0 * 12544 * 4096 * 1024))
     work.append(("attention fwd+bwd", attn, 3.5 * 4.0 * 8 * H * L * L * 64))
     work.append(("layernorm bwd", lambda: ops.layernorm_bwd(dyl, xr, mean, rstd, gam, dres=dres, dx=dres, dxT=dxT), 203e6))
+    base = None
     for name, fn, unit in work:
         r = s.measure(fn, 4.0 if name != "idle" else 1.5, unit)
-        print("%-22s %8.3f ms/iter  %8.1f T(FLOP|B)/s   power mean %s W  max %s W   sclk mean %s MHz   (%d samples)"
-              % (name, r["ms"], r["rate"] / 1e12, "%.0f" % r["power_mean"] if r["power_mean"] else "n/a", "%.0f" % r["power_max"] if r["power_max"] else "n/a",
-                 "%.0f" % r["sclk_mean"] if r["sclk_mean"] else "n/a", r["n"]), flush=True)
+        if name == "idle":
+            base = r["per"]
+            print("idle: per-node mean power", ["%.0f" % v[0] for v in r["per"].values()], flush=True)
+            continue
+        if s.card is None:          # our GPU = the node whose power rose most over idle
+            s.card = max(s.nodes, key=lambda n_: r["per"][n_][0] - base[n_][0])
+            print("our GPU is", s.card, "(+%.0f W over idle; cap %s uW)" % (r["per"][s.card][0] - base[s.card][0], s.cap[s.card]), flush=True)
+        pm, px, cm, cmin = r["per"][s.card]
+        print("%-22s %8.3f ms/iter  %8.1f T(FLOP|B)/s   power mean %4.0f W  max %4.0f W   sclk mean %4.0f MHz  min %4.0f MHz   (%d samples)"
+              % (name, r["ms"], r["rate"] / 1e12, pm, px, cm, cmin, r["n"]), flush=True)
     lib.pa_debug_set(5, 0)
-    s.run = False
+    s.alive = False
 
 
 if __name__ == "__main__":
