@@ -130,6 +130,15 @@ int pa_patch_embed_fwd(int dtype, const float* imgs, const float* tgts, const vo
                        const float* mask_token, const float* seg_x, const float* seg_y, const float* pos,
                        const unsigned char* mask, int mask_batch_stride, const float* type_cls, const float* type_ins,
                        const float* seg_type, float* tokens, int batch, int Hp, int Wp, int P, int D, hipStream_t stream);
+/* bf16 fast path (P % 8 == 0 and 3*P*P % 128 == 0, i.e. every reference factory): materialise the im2col operand once
+ * (cols: bf16 [2*B*L, 3*P*P], also the X operand of the weight gradient: pa_linear_wgrad(dpe, cols)) and run the contraction on the
+ * 256x256 LDS-DMA kernel.  pa_patch_cols_ok() says whether the shape qualifies; pa_patch_embed_fwd / _wgrad serve every other case. */
+int pa_patch_cols_ok(int batch, int L, int P, int D);
+int pa_patch_im2col(const float* imgs, const float* tgts, void* cols, int batch, int Hp, int Wp, int P, hipStream_t stream);
+int pa_patch_embed_fwd_cols(const void* cols, const void* w /*bf16 [D, ldw]*/, int64_t ldw, const float* bias, const float* mask_token,
+                            const float* seg_x, const float* seg_y, const float* pos, const unsigned char* mask, int mask_batch_stride,
+                            const float* type_cls, const float* type_ins, const float* seg_type, float* tokens, int batch, int L, int K,
+                            int D, hipStream_t stream);
 int64_t pa_patch_embed_wgrad_workspace_bytes(int D, int P);
 int pa_patch_embed_wgrad(int dtype, const void* dpe /*T [2BL, D]*/, const float* imgs, const float* tgts,
                          float* dw /*f32 [D, 3*P*P]*/, void* workspace, int batch, int Hp, int Wp, int P, int D,

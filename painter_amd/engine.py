@@ -197,10 +197,17 @@ class HotPath:
         S.drop = drop_scales
         pe = P["pos_embed"][0, c.cls:]
         pos = ops.pos_fwd(self.pos_operator(dev)[0], pe, L, D)
-        x = ops.patch_embed_fwd(T, imgs, tgts, self.w_patch(P), P["patch_embed.proj.bias"],
-                                P["mask_token"], P["segment_token_x"], P["segment_token_y"], pos, mask_u8,
-                                P.get("type_token_cls") if c.seggpt else None, P.get("type_token_ins") if c.seggpt else None,
-                                seg_type if c.seggpt else None, B, c.Hp, c.Wp, c.P, D)
+        tok_args = (P["patch_embed.proj.bias"], P["mask_token"], P["segment_token_x"], P["segment_token_y"], pos, mask_u8,
+                    P.get("type_token_cls") if c.seggpt else None, P.get("type_token_ins") if c.seggpt else None,
+                    seg_type if c.seggpt else None)
+        S.cols = None
+        if ops.patch_cols_ok(T, B, L, c.P, D):           # bf16, P % 8 == 0: materialised im2col operand + the 256 x 256 GEMM (kept for the weight gradient)
+            cols = ops.patch_im2col(imgs, tgts, B, c.Hp, c.Wp, c.P)
+            x = ops.patch_embed_fwd_cols(cols, self.w_patch(P), *tok_args, B, L, D)
+            if need_grad:
+                S.cols = cols
+        else:
+            x = ops.patch_embed_fwd(T, imgs, tgts, self.w_patch(P), *tok_args, B, c.Hp, c.Wp, c.P, D)
         concat = torch.empty((B * L, 4 * D), dtype=T, device=dev)
         S.blocks, S.taps = [], []
         Bc = 2 * B
@@ -421,7 +428,10 @@ class HotPath:
         G["norm.weight"], G["norm.bias"] = dnorm[0], dnorm[1]
         # ---- token assembly + patch embed
         dpe, sums = ops.tokens_bwd(T, dx, S.mask, B, L, D)
-        G["patch_embed.proj.weight"] = ops.patch_embed_wgrad(dpe, S.imgs, S.tgts, B, c.Hp, c.Wp, c.P, D).view(D, 3, c.P, c.P)
+        if S.cols is not None:
+            G["patch_embed.proj.weight"] = ops.linear_wgrad(dpe, S.cols).view(D, 3, c.P, c.P)
+        else:
+            G["patch_embed.proj.weight"] = ops.patch_embed_wgrad(dpe, S.imgs, S.tgts, B, c.Hp, c.Wp, c.P, D).view(D, 3, c.P, c.P)
         G["patch_embed.proj.bias"] = ops.colsum(dpe)
         dposemb = torch.zeros_like(P["pos_embed"])
         ops.pos_bwd(self.pos_operator(dev)[1], sums[0], sums[1], dposemb[0, c.cls:], c.src * c.src, D)

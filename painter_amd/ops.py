@@ -259,6 +259,27 @@ def patch_embed_fwd(T, imgs, tgts, w, bias, mask_token, seg_x, seg_y, pos, mask_
     return tokens
 
 
+def patch_cols_ok(T, batch, L, P, D):
+    """Does the bf16 im2col + gemm256 fast path of the patch embedding take this shape?"""
+    return T == torch.bfloat16 and bool(lib.pa_patch_cols_ok(batch, L, P, D))
+
+
+def patch_im2col(imgs, tgts, batch, Hp, Wp, P):
+    """-> bf16 [2*B*L, 3*P*P]: the conv's im2col operand (rows = x-stream tokens then y-stream tokens, k = c*P*P + ph*P + pw)."""
+    cols = torch.empty((2 * batch * Hp * Wp, 3 * P * P), dtype=torch.bfloat16, device=imgs.device)
+    check(lib.pa_patch_im2col(p(imgs), p(tgts), p(cols), batch, Hp, Wp, P, stream()), "pa_patch_im2col")
+    return cols
+
+
+def patch_embed_fwd_cols(cols, w, bias, mask_token, seg_x, seg_y, pos, mask_u8, type_cls, type_ins, seg_type, batch, L, D):
+    tokens = torch.empty((2 * batch * L, D), dtype=torch.float32, device=cols.device)
+    mbs = 0 if mask_u8.shape[0] == 1 else mask_u8.stride(0)
+    assert w.dtype == torch.bfloat16 and w.shape[0] == D and w.stride(1) == 1 and cols.is_contiguous()
+    check(lib.pa_patch_embed_fwd_cols(p(cols), p(w), w.stride(0), p(bias), p(mask_token), p(seg_x), p(seg_y), p(pos), p(mask_u8), mbs,
+                                      p(type_cls), p(type_ins), p(seg_type), p(tokens), batch, L, cols.shape[1], D, stream()), "pa_patch_embed_fwd_cols")
+    return tokens
+
+
 def patch_embed_wgrad(dpe, imgs, tgts, batch, Hp, Wp, P, D):
     dw = torch.empty((D, 3 * P * P), dtype=torch.float32, device=dpe.device)
     ws = workspace(lib.pa_patch_embed_wgrad_workspace_bytes(D, P), dpe.device)

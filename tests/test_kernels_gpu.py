@@ -611,6 +611,17 @@ def test_patch_embed_and_token_assembly_in_isolation(T, seggpt, P):
     cols = lambda im: torch.nn.functional.unfold(im.to(T).double(), P, stride=P).transpose(1, 2).reshape(B * L, 3 * P * P)
     refw = dpe.double()[:B * L].t() @ cols(imgs) + dpe.double()[B * L:].t() @ cols(tgts)
     assert relerr(dw, refw) < (2e-6 if T == torch.float32 else 2e-5), relerr(dw, refw)
+    if ops.patch_cols_ok(T, B, L, P, D):
+        # the bf16 fast path of the engine: materialised im2col operand (bit-exact: index math + one rounding) + the 256 x 256 GEMM with
+        # the same token-assembly epilogue; the weight gradient is the ordinary nn.Linear weight gradient on that operand
+        cm = ops.patch_im2col(imgs, tgts, B, Hp, Wp, P)
+        assert torch.equal(cm.float().cpu(), torch.cat([cols(imgs), cols(tgts)]).float().cpu())
+        x2 = ops.patch_embed_fwd_cols(cm, wop, bias, mask_token, seg_x, seg_y, pos, mask.to(torch.uint8), tcls if seggpt else None,
+                                      tins if seggpt else None, seg_type if seggpt else None, B, L, D)
+        assert relerr(x2, ref) < 3e-3, relerr(x2, ref)
+        assert relerr(ops.linear_wgrad(dpe, cm), refw) < 2e-5
+    else:
+        assert T == torch.float32 or P % 8
 
 
 @pytest.mark.parametrize("src,Hp,Wp", [(14, 56, 28), (16, 64, 32), (14, 8, 4), (14, 14, 14)])

@@ -22,7 +22,7 @@ for s in "$@"; do
     ilv)       PAINTER_AMD_LIB=painter_amd/lib/libpainter_hip_ilv.so timeout 900 python tools/gemm_ilv_ab.py step > gpurun_out/ilv.log 2>&1; echo "ilv rc=$?"; tail -40 gpurun_out/ilv.log ;;
     power)     PAINTER_AMD_LIB=painter_amd/lib/libpainter_hip_ilv.so timeout 600 python tools/power_probe.py > gpurun_out/power.log 2>&1; echo "power rc=$?"; tail -12 gpurun_out/power.log ;;
     ilvprof)   (cd /tmp && for i in 0 2; do PA_G256_ILV=$i PAINTER_AMD_LIB=$OLDPWD/painter_amd/lib/libpainter_hip_ilv.so PAINTER_AMD_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_ilv$i -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_ilv$i.log 2>&1; done); echo "ilvprof done"; ls gpurun_out/prof_ilv0 gpurun_out/prof_ilv2 | head ;;
-    fixtests)  timeout 600 python -m pytest tests/test_parallel_gpu.py tests/test_kernels_gpu.py -m gpu -q -x -k "two_ranks or abs_pos or generations" > gpurun_out/fixtests.log 2>&1; echo "fixtests rc=$?"; tail -5 gpurun_out/fixtests.log ;;
+    fixtests)  timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -x -k "patch_embed or small or h14_fp32 or seggpt" > gpurun_out/fixtests.log 2>&1; echo "fixtests rc=$?"; tail -5 gpurun_out/fixtests.log ;;
     *)         echo "unknown section $s" ;;
   esac
 done
