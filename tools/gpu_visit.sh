@@ -23,6 +23,10 @@ for s in "$@"; do
     power)     PAINTER_AMD_LIB=painter_amd/lib/libpainter_hip_ilv.so timeout 600 python tools/power_probe.py > gpurun_out/power.log 2>&1; echo "power rc=$?"; tail -12 gpurun_out/power.log ;;
     ilvprof)   (cd /tmp && for i in 0 2; do PA_G256_ILV=$i PAINTER_AMD_LIB=$OLDPWD/painter_amd/lib/libpainter_hip_ilv.so PAINTER_AMD_SIDE_STREAM=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_ilv$i -o p -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_ilv$i.log 2>&1; done); echo "ilvprof done"; ls gpurun_out/prof_ilv0 gpurun_out/prof_ilv2 | head ;;
     fixtests)  timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -x -k "patch_embed or small or h14_fp32 or seggpt" > gpurun_out/fixtests.log 2>&1; echo "fixtests rc=$?"; tail -5 gpurun_out/fixtests.log ;;
+    knobs)     timeout 600 python tools/knob_sweep.py > gpurun_out/knobs.log 2>&1; echo "knobs rc=$?"; tail -9 gpurun_out/knobs.log ;;
+    seggpt)    timeout 600 python tools/seggpt_bench.py > gpurun_out/seggpt.log 2>&1; echo "seggpt rc=$?"; tail -4 gpurun_out/seggpt.log ;;
+    pmcattn)   (cd /tmp && for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
+                  n=$(echo $c | cut -d' ' -f1); timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OLDPWD/gpurun_out/pmcattn_$n -o pmc -- env PYTHONPATH=$OLDPWD python $OLDPWD/tools/attn_bench.py > $OLDPWD/gpurun_out/pmcattn_$n.log 2>&1; done); echo "pmcattn done" ;;
     *)         echo "unknown section $s" ;;
   esac
 done
