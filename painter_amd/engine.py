@@ -39,7 +39,7 @@ def _configure_library():
     if _configured:
         return
     from ._lib import lib
-    lib.pa_debug_set(6, 4 if _SIDE_STREAM else 0)       # K splits of the rel-pos table-gradient GEMM beside the main chain: 16 -> 54.54, 4 -> 54.35, 2 -> 55.0 ms/step
+    lib.pa_debug_set(6, 8 if _SIDE_STREAM else 0)       # K splits of the rel-pos table-gradient GEMM beside the main chain: round 2: 16 -> 54.54, 4 -> 54.35, 2 -> 55.0 ms/step; round 3 (tools/knob_sweep.py): 2 -> 56.18, 4 -> 55.10, 8 -> 54.89
     lib.pa_debug_set(3, 128 if _SIDE_STREAM else 0)     # wgrad GEMM workgroup target (gemm.hip: wgrad_fast_splits); round-2 sweep: 64 -> 59.7, 96 -> 57.7, 128 -> 57.7, 192 -> 58.9, 256 -> 59.2 ms/step
     _configured = True
 
