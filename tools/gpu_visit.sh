@@ -5,19 +5,24 @@
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
+ulimit -c 0                     # a faulting GPU makes every python process abort: without this each abort writes a multi-GB core (minutes)
+# a faulty box shows up in the first H2D copy: check once, and do nothing else on such a box (round 3 lost 50 GPU-minutes to one)
+if ! timeout 120 python -c "import torch; x = torch.randn(1 << 20).cuda(); assert abs(float((x * 2).sum()) - 2 * float(x.sum())) < 1e-2; torch.cuda.synchronize(); print('gpu sanity ok', torch.cuda.get_device_name(0))"; then
+  echo "GPU SANITY CHECK FAILED -- not running anything on this box"; exit 3
+fi
 HEAD=${PAINTER_AMD_GIT_HEAD:-unknown}
 export PAINTER_AMD_GIT_HEAD=$HEAD
 for s in "$@"; do
   case $s in
     tests)     timeout 1500 python -m pytest tests -m gpu -q -s > gpurun_out/tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/tests.log ;;
     newtests)  timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -s -k "head_dim_80 or h14 or loss_variants or patch_embed or vit_large or c_abi" > gpurun_out/newtests.log 2>&1; echo "newtests rc=$?"; tail -15 gpurun_out/newtests.log ;;
-    bench)     timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-600 gpurun_out/bench.json ;;
-    benchfast) timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-optimizer > gpurun_out/benchfast.json 2> gpurun_out/benchfast.err; echo "benchfast rc=$?"; cut -c1-400 gpurun_out/benchfast.json ;;
-    huge)      timeout 900 python bench.py --model vit_huge --steps 5 --warmup 2 --no-cpu-baseline --min-seconds 2 > gpurun_out/bench_huge.json 2> gpurun_out/bench_huge.err; echo "huge rc=$?"; cut -c1-600 gpurun_out/bench_huge.json; tail -3 gpurun_out/bench_huge.err ;;
-    profile)   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_two_stream -o two -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_two.log 2>&1
-                PAINTER_AMD_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_one_stream -o one -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_one.log 2>&1); echo "profile done"; ls gpurun_out/prof_one_stream gpurun_out/prof_two_stream 2>/dev/null | head ;;
+    bench)     timeout 330 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-600 gpurun_out/bench.json ;;
+    benchfast) timeout 240 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-optimizer > gpurun_out/benchfast.json 2> gpurun_out/benchfast.err; echo "benchfast rc=$?"; cut -c1-400 gpurun_out/benchfast.json ;;
+    huge)      timeout 200 python bench.py --model vit_huge --steps 5 --warmup 2 --no-cpu-baseline --min-seconds 2 > gpurun_out/bench_huge.json 2> gpurun_out/bench_huge.err; echo "huge rc=$?"; cut -c1-600 gpurun_out/bench_huge.json; tail -3 gpurun_out/bench_huge.err ;;
+    profile)   (cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_two_stream -o two -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_two.log 2>&1
+                PAINTER_AMD_SIDE_STREAM=0 timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_one_stream -o one -- python $OLDPWD/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_one.log 2>&1); echo "profile done"; ls gpurun_out/prof_one_stream gpurun_out/prof_two_stream 2>/dev/null | head ;;
     pmc)       (cd /tmp && for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
-                  n=$(echo $c | cut -d' ' -f1); PAINTER_AMD_SIDE_STREAM=0 timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OLDPWD/gpurun_out/pmc_$n -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/pmc_$n.log 2>&1; done); echo "pmc done" ;;
+                  n=$(echo $c | cut -d' ' -f1); PAINTER_AMD_SIDE_STREAM=0 timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OLDPWD/gpurun_out/pmc_$n -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/pmc_$n.log 2>&1; done); echo "pmc done" ;;
     overlap)   PAINTER_AMD_DDP_SELFTEST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29544 timeout 600 python tools/gradsync_overlap.py > gpurun_out/overlap.log 2>&1; echo "overlap rc=$?"; tail -12 gpurun_out/overlap.log ;;
     ilv)       PAINTER_AMD_LIB=painter_amd/lib/libpainter_hip_ilv.so timeout 900 python tools/gemm_ilv_ab.py step > gpurun_out/ilv.log 2>&1; echo "ilv rc=$?"; tail -40 gpurun_out/ilv.log ;;
     power)     PAINTER_AMD_LIB=painter_amd/lib/libpainter_hip_ilv.so timeout 600 python tools/power_probe.py > gpurun_out/power.log 2>&1; echo "power rc=$?"; tail -12 gpurun_out/power.log ;;
@@ -27,6 +32,7 @@ for s in "$@"; do
     seggpt)    timeout 600 python tools/seggpt_bench.py > gpurun_out/seggpt.log 2>&1; echo "seggpt rc=$?"; tail -4 gpurun_out/seggpt.log ;;
     pmcattn)   (cd /tmp && for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
                   n=$(echo $c | cut -d' ' -f1); timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OLDPWD/gpurun_out/pmcattn_$n -o pmc -- env PYTHONPATH=$OLDPWD python $OLDPWD/tools/attn_bench.py > $OLDPWD/gpurun_out/pmcattn_$n.log 2>&1; done); echo "pmcattn done" ;;
+    finaltests) timeout 300 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -s -x -k "gemm256 or vit_large_b8 or abs_pos" > gpurun_out/finaltests.log 2>&1; echo "finaltests rc=$?"; tail -4 gpurun_out/finaltests.log ;;
     *)         echo "unknown section $s" ;;
   esac
 done

@@ -9,8 +9,9 @@ import glob
 import json
 import sys
 
-KERNELS = {"fc1": "Epi4BiasGelu", "attn_fwd": "a3::fwd_kernel", "wgrad": "Epi4Slab", "dgrad": "gemm256_kernelILb0ELb1E8Epi4Bias",
-           "attn_bwd_dq": "a3::bwd_dq_kernel", "attn_bwd_dkv": "a3::bwd_dkv_kernel"}
+# every substring of a tuple has to occur in the kernel name (the mangled dgrad name carries the ILV template argument in the middle)
+KERNELS = {"fc1": ("Epi4BiasGelu",), "attn_fwd": ("a3::fwd_kernel",), "wgrad": ("Epi4Slab",), "dgrad": ("gemm256_kernelILb0ELb1E", "8Epi4BiasIDF16b"),
+           "attn_bwd_dq": ("a3::bwd_dq_kernel",), "attn_bwd_dkv": ("a3::bwd_dkv_kernel",)}
 
 
 def per_launch(path, counter):
@@ -20,7 +21,7 @@ def per_launch(path, counter):
             if r["Counter_Name"] != counter:
                 continue
             for key, pat in KERNELS.items():
-                if pat in r["Kernel_Name"]:
+                if all(p_ in r["Kernel_Name"] for p_ in pat):
                     vals[key].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
     return vals
 
