@@ -14,7 +14,7 @@ HEAD=${PAINTER_AMD_GIT_HEAD:-unknown}
 export PAINTER_AMD_GIT_HEAD=$HEAD
 for s in "$@"; do
   case $s in
-    tests)     timeout 1500 python -m pytest tests -m gpu -q -s > gpurun_out/tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/tests.log ;;
+    tests)     timeout 480 python -m pytest tests -m gpu -q -s > gpurun_out/tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/tests.log ;;
     newtests)  timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -s -k "head_dim_80 or h14 or loss_variants or patch_embed or vit_large or c_abi" > gpurun_out/newtests.log 2>&1; echo "newtests rc=$?"; tail -15 gpurun_out/newtests.log ;;
     bench)     timeout 330 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.json 2> gpurun_out/bench.err; echo "bench rc=$?"; cut -c1-600 gpurun_out/bench.json ;;
     benchfast) timeout 240 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-optimizer > gpurun_out/benchfast.json 2> gpurun_out/benchfast.err; echo "benchfast rc=$?"; cut -c1-400 gpurun_out/benchfast.json ;;
