@@ -77,7 +77,7 @@ class HotPathConfig:
             err.append("head_dim must be 64 (the reference factories) or 80 (ViT-H/14, BASELINE configs[4]); got %d" % hd)
         if self.dec != 64: err.append("decoder_embed_dim must be 64 (got %d)" % self.dec)
         if self.L % 32 or self.Hp % 4 or self.Wp % 4: err.append("token grid %dx%d must have Hp,Wp %% 4 == 0 and L %% 32 == 0" % (self.Hp, self.Wp))
-        if self.H % self.P or self.W % self.P or (self.W * self.P) % 4: err.append("image %dx%d is not a whole number of %d-pixel patches" % (self.H, self.W, self.P))
+        if self.H % self.P or self.W % self.P or self.W % 4: err.append("image %dx%d must be a whole number of %d-pixel patches, width a multiple of 4" % (self.H, self.W, self.P))
         if self.D % 8 or self.hidden % 8: err.append("embed/hidden dims must be multiples of 8")
         if not self.use_rel_pos: err.append("use_rel_pos=False is not built (the reference factories always enable it)")
         if self.H != 2 * self.W: err.append("img_size must be (2W, W) (patchify asserts H == 2W, models_painter.py:361)")
