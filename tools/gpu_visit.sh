@@ -33,6 +33,7 @@ for s in "$@"; do
     pmcattn)   (cd /tmp && for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS GRBM_GUI_ACTIVE" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES"; do
                   n=$(echo $c | cut -d' ' -f1); timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OLDPWD/gpurun_out/pmcattn_$n -o pmc -- env PYTHONPATH=$OLDPWD python $OLDPWD/tools/attn_bench.py > $OLDPWD/gpurun_out/pmcattn_$n.log 2>&1; done); echo "pmcattn done" ;;
     finaltests) timeout 300 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -s -x -k "gemm256 or vit_large_b8 or abs_pos" > gpurun_out/finaltests.log 2>&1; echo "finaltests rc=$?"; tail -4 gpurun_out/finaltests.log ;;
+    lnpatch)   timeout 200 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_parallel_gpu.py tests/test_boundary_gpu.py -m gpu -q -s -x -k "layernorm or small or h14_fp32 or b8_train_bf16 or (two_ranks and GradSync) or bare_module" > gpurun_out/lnpatch.log 2>&1; echo "lnpatch rc=$?"; tail -4 gpurun_out/lnpatch.log ;;
     *)         echo "unknown section $s" ;;
   esac
 done
