@@ -43,3 +43,28 @@ def test_reference_drivers_import_and_touch_only_attributes_our_modules_have():
     missing = sorted(a for a in used_seg if a not in probe_seg)
     assert not missing, missing
     assert {"unpatchify", "patch_size"} <= used | used_seg          # the scan does see what the drivers use
+
+
+def test_run_one_image_expectation_of_the_gpu_test_holds_for_the_reference_model_itself():
+    """tests/test_reference_engine_gpu.py compares the unmodified `run_one_image` on OUR SegGPT module with a picture computed from the CPU
+    oracle.  Here the same comparison is made with the REFERENCE's own model in the driver (CPU, tiny config): it pins the test's
+    expectation, so a failure on a GPU box can only come from our module."""
+    import torch
+
+    from oracle import painter_oracle as O
+    from tests.golden.make_golden import build_reference
+    eng = ref_import.load_reference_seggpt_engine()
+    cfg = O.tiny_config(seggpt=True)
+    model, P = build_reference(cfg, 5)
+    model.eval()
+    model.seg_type = "instance"
+    imgs, tgts, _, _ = O.synthetic_batch(cfg, 2, 9, "half")
+    out = eng.run_one_image(imgs.permute(0, 2, 3, 1).double().numpy(), tgts.permute(0, 2, 3, 1).double().numpy(), model, torch.device("cpu"))
+    L = cfg.grid[0] * cfg.grid[1]
+    mask = torch.zeros(1, L)
+    mask[:, L // 2:] = 1
+    with torch.no_grad():
+        _, yo, _ = O.forward(P, cfg, imgs, tgts, mask, torch.ones_like(tgts), torch.ones(2, 1), 0)
+    y = O.unpatchify(yo, cfg.patch_size).permute(0, 2, 3, 1)
+    ref = torch.clip((y[0, y.shape[1] // 2:] * torch.tensor(O.IMAGENET_STD) + torch.tensor(O.IMAGENET_MEAN)) * 255, 0, 255)
+    assert out.shape == ref.shape and float((out - ref).abs().max()) < 1e-2
