@@ -37,12 +37,13 @@ enum {
 };
 
 /* Bumped whenever an entry point's argument list changes (2: `tables` in pa_attn_fwd / pa_attn_bwd; 3: `head_dim` in the attention and
- * rel-pos entry points).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
-#define PA_ABI_VERSION 3
+ * rel-pos entry points; 4: `dxT_colsum` in pa_layernorm_bwd, `relpos_part` in pa_attn_bwd).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
+#define PA_ABI_VERSION 4
 int pa_abi_version(void);
 /* diagnostics only (tools/): which = 0 start-up stagger of alternate workgroup rows of the 256x256 GEMM in shader cycles,
  * 1 drop that kernel's epilogue stores (never set by the product path); 3 = TUNING, set by the engine: target number of workgroups
- * of the weight-gradient GEMM (0 = 256, the whole chip; 64 when the weight gradients run on a side stream). */
+ * of the weight-gradient GEMM (0 = 256, the whole chip; 64 when the weight gradients run on a side stream); 6 = K splits of the
+ * rel-pos table-gradient GEMM; 7 = rel-pos table gradient inside the generation-3 dQ kernel: 0 default (on), 1 off, 2 on (tests). */
 int pa_debug_set(int which, int value);
 
 /* ---- nn.Linear: y = x W^T + b.  models_painter.py:76 (qkv), :87 (proj), timm Mlp fc1/fc2 (:201,:230) ---- */
@@ -71,11 +72,12 @@ int pa_layernorm_fwd(int dtype, const float* x, int64_t ldx, const float* gamma,
                      int R, int D, hipStream_t stream);
 int64_t pa_layernorm_bwd_workspace_bytes(int R, int D);
 /* dx = (dres ? dres : 0) + LN'(dy); dres may alias dx.  dxT (optional, T) = rowscale[row/rows_per_sample] * dx.
- * dgamma_dbeta: f32 [2, D], overwritten. */
+ * dgamma_dbeta: f32 [2, D], overwritten.  dxT_colsum (optional, f32 [D], needs dxT): the column sums of dxT as stored (rounded to
+ * T) -- dxT is the dY of the nn.Linear in front of this norm's residual branch, so this is that layer's bias gradient, fused here. */
 int pa_layernorm_bwd(int dtype, const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                      const float* rstd, const float* gamma, const float* dres, float* dx, int64_t lddx, void* dxT,
-                     int64_t lddxT, const float* rowscale, int rows_per_sample, float* dgamma_dbeta, void* workspace,
-                     int R, int D, hipStream_t stream);
+                     int64_t lddxT, const float* rowscale, int rows_per_sample, float* dgamma_dbeta, float* dxT_colsum,
+                     void* workspace, int R, int D, hipStream_t stream);
 
 /* ---- Attention with decomposed rel-pos bias: models_painter.py:76-86 + util/vitdet_utils.py:63-125 ---- */
 int pa_relpos_rows_padded(int Hp, int Wp);
@@ -100,7 +102,10 @@ int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void*
 /* autograd of pa_attn_fwd (no reference source: torch autograd of the lines above).
  *   delta  : f32 [batch*heads, L] = rowsum(dO o O)                      (pa_attn_bwd_delta)
  *   dqkv   : T, same layout as qkv (dq | dk | dv)
- *   dG     : T [batch*L, heads*NRP] r-space bias gradient, consumed by pa_attn_bwd_relpos
+ *   dG     : T [batch*L, heads*NRP] r-space bias gradient, consumed by pa_attn_bwd_relpos (NULL when relpos_part is given)
+ *   relpos_part : NULL, or pa_attn_bwd_relpos_partials_bytes() (> 0 only where the 28-token-wide bf16 kernels run and `tables` is
+ *            given) of device scratch: the dQ kernel then contracts d rel_pos itself -- one fp32 [NRP, hd] partial per workgroup --
+ *            dG is not written, and pa_attn_bwd_relpos_reduce() sums the partials into drcat in a fixed order (deterministic)
  *   aux    : scratch of pa_attn_bwd_aux_bytes()
  *   tables : what pa_attn_fwd wrote (NULL: the backward recomputes the bias tables itself, generation-2 kernels);
  *            the backward adds lse / delta fields to it
@@ -111,10 +116,13 @@ int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* rel_pos_w, 
 int pa_attn_bwd_delta(int dtype, const void* out, int64_t ldo, const void* dout, int64_t lddo, float* delta, int batch,
                       int L, int heads, int head_dim, hipStream_t stream);
 int64_t pa_attn_bwd_aux_bytes(int batch, int L, int heads, int Hp, int Wp);
+int64_t pa_attn_bwd_relpos_partials_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp, int head_dim);
 int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, const void* rcatT, const void* dout,
-                int64_t lddo, const float* lse, const float* delta, void* dqkv, void* dG, void* aux, void* tables,
-                int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t stream);
+                int64_t lddo, const float* lse, const float* delta, void* dqkv, void* dG, void* relpos_part, void* aux,
+                void* tables, int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t stream);
 int64_t pa_attn_bwd_relpos_workspace_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp, int head_dim);
+int pa_attn_bwd_relpos_reduce(const void* relpos_part, float* drcat, void* workspace, int batch, int L, int heads, int Hp, int Wp,
+                              int head_dim, hipStream_t stream);
 int pa_attn_bwd_relpos(int dtype, const void* dG, const void* qkv, int64_t ldq, float* drcat, void* workspace,
                        int batch, int L, int heads, int Hp, int Wp, int head_dim, hipStream_t stream);
 

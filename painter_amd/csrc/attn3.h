@@ -7,5 +7,9 @@ bool attn3_ok(int L, int Hp, int Wp);
 int64_t attn3_table_bytes(int Bn, int L, int H, int Hp, int Wp);
 int attn3_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t ldo, float* lse, void* tables, int Bn, int L, int H,
               int Hp, int Wp, float scale, hipStream_t st);
+// part != NULL (attn3_relpos_partials_bytes() of fp32 scratch): the dQ kernel contracts the rel-pos table gradient itself and writes one
+// partial per workgroup there instead of dG; attn3_relpos_reduce() sums the partials into drcat [NRP][64]
 int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const float* delta,
-              void* tables, bf16* dqkv, bf16* dG, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st);
+              void* tables, bf16* dqkv, bf16* dG, float* part, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st);
+int64_t attn3_relpos_partials_bytes(int Bn, int L, int H, int Hp, int Wp);       // 0: not fused for this grid (or PA_ATTN3_FUSE_RELPOS=0)
+int attn3_relpos_reduce(const float* part, float* drcat, float* tmp, int Bn, int L, int H, int Hp, int Wp, hipStream_t st);

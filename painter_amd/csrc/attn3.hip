@@ -61,7 +61,7 @@ __global__ __launch_bounds__(NT, STAGES == 1 ? 4 : 2) void fwd_kernel(const bf16
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, ql = lane & 31;
     int blk, bh;
-    wg_coords(nblk, xcd_map, blk, bh);
+    wg_coords(nblk, xcd_map, blk, bh, (L / 32) / NW);
     const int b = bh / H, h = bh % H, D = H * ATT_HD;
     const bf16* base = qkv + (size_t)b * L * ldq + h * ATT_HD;
     const bf16* kbase = base + D;
@@ -203,12 +203,19 @@ __global__ __launch_bounds__(NT, STAGES == 1 ? 4 : 2) void fwd_kernel(const bf16
 // NDL = true keeps -Delta in 16 accumulator-init registers (dP - Delta comes out of the MFMA chain); false adds it on the VALU
 // diagnostics (pa_attn_trace): s_memtime stamps of two workgroups' waves 0 / 1 at seven points of every tile iteration
 __device__ unsigned long long g_trace[2 * 2 * 64 * 8];
-template <int MINW, bool NDL, bool TR = false>
+// FUSE: the rel-pos table gradient d Rcat[r][d] = sum_q dG[q][r] Q[q][d] is contracted here, per workgroup, instead of writing the
+// per-query bias gradient dG (bf16 [R, heads * NRP], 77 MB per launch at the ViT-L shape) for a gather GEMM over it: after the r-space
+// loop the waves put their dG rows (bf16 [32 q][NRP], kept in registers through that loop) and their Q rows into LDS images -- every
+// other LDS region is dead by then -- and wave w contracts r-blocks w, w + 4 over all of the workgroup's queries through the
+// transposing reads (d Rcat^T[d][r] += Q^T[d][q] dG^T[r][q]); one fp32 [NRP][64] partial per workgroup goes to `part`
+// (pa_attn_bwd_relpos_reduce sums them in a fixed order).  Needs NRP <= 16 * NSMAX.
+constexpr int NSMAX = 12;
+template <int MINW, bool NDL, bool TR = false, bool FUSE = false>
 __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcatT,
                                                           const bf16* __restrict__ dout, size_t lddo, const float* __restrict__ lse,
                                                           const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv,
-                                                          bf16* __restrict__ dG, int L, int H, int Hp, int NRP, float scale, int nblk,
-                                                          int xcd_map, int abl) {
+                                                          bf16* __restrict__ dG, float* __restrict__ part, int L, int H, int Hp, int NRP,
+                                                          float scale, int nblk, int xcd_map, int abl) {
     // abl (diagnostics, PA_ATTN3_DQ_ABL; results are WRONG with any bit set): 1 no r-space loop after the key loop, 2 no dG stores,
     // 4 no dQ store, 16 no key loop, 32 no gather in the r-space loop, 64 no MFMA in the r-space loop
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -224,7 +231,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     };
     coarse(60);
     int blk, bh;
-    wg_coords(nblk, xcd_map, blk, bh);
+    wg_coords(nblk, xcd_map, blk, bh, (L / 32) / NW);
     const int b = bh / H, h = bh % H, D = H * ATT_HD;
     const bf16* base = qkv + (size_t)b * L * ldq + h * ATT_HD;
     const bf16* kbase = base + D;
@@ -401,6 +408,11 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     // becomes the fp32 kw-gradient table [wave][32 q][28], the K/V region the per-wave dQ staging tiles
     float* twg = reinterpret_cast<float*>(eimg + wave * (32 * WP * 4));
     unsigned char* stg = smem + wave * IMG;
+    uint4 gfs[FUSE ? NSMAX : 1];
+    if constexpr (FUSE) {
+#pragma unroll
+        for (int s = 0; s < NSMAX; ++s) gfs[s] = zero4();
+    }
     if (valid) {
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
@@ -460,7 +472,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         bf16x8 rf[2] = {rfrag(r0, 0), rfrag(r1, 0)};
         float gcur[8];
         gather(0, gcur);
-        for (int s = 0; s < ((abl & 1) ? 0 : nstep); ++s) {
+        auto rstep = [&](int s, uint4& keep) {
             const int sn = min(s + 1, nstep - 1);
             const bf16x8 rn[2] = {rfrag(r0, sn), rfrag(r1, sn)};
             float gnext[8];
@@ -471,7 +483,8 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
                 gather(sn, gnext);
             }
             const bf16x8 gf = packfrag(gcur);
-            if (!(abl & 2)) *reinterpret_cast<uint4*>(dgrow + 16 * s + 8 * g) = __builtin_bit_cast(uint4, gf);
+            if constexpr (FUSE) keep = __builtin_bit_cast(uint4, gf);
+            else if (!(abl & 2)) *reinterpret_cast<uint4*>(dgrow + 16 * s + 8 * g) = __builtin_bit_cast(uint4, gf);
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 if (!(abl & 64)) dq[db] = mfma(rf[db], gf, dq[db]);
@@ -479,9 +492,52 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) gcur[t] = gnext[t];
+        };
+        if constexpr (FUSE) {           // fully unrolled: gfs[] has to stay in registers
+#pragma unroll
+            for (int s = 0; s < NSMAX; ++s)
+                if (s < ((abl & 1) ? 0 : nstep)) rstep(s, gfs[s]);
+        } else {
+            uint4 none;
+            for (int s = 0; s < ((abl & 1) ? 0 : nstep); ++s) rstep(s, none);
         }
         stage_rows(stg, dq, 1.f, lane);
         if (!(abl & 4)) write_rows(stg, dqkv + (size_t)(b * L + qt * 32) * ldq + h * ATT_HD, ldq, lane);
+    }
+    if constexpr (FUSE) {
+        __syncthreads();                                     // every wave is done with the tables, Rcat^T and its dQ staging tile
+        const int nimg = (NRP + 63) >> 6;                    // per wave: nimg images [32 q][64 r] of dG, then one [32 q][64 d] image of Q
+        unsigned char* wimg = smem + wave * (nimg + 1) * IMG;
+        if (valid) {
+            const int rsw = vsw(ql);
+#pragma unroll
+            for (int s = 0; s < NSMAX; ++s)
+                if (s < NRP / 16) *reinterpret_cast<uint4*>(wimg + (s >> 2) * IMG + ql * 128 + ((((2 * s + g) & 7) ^ rsw) << 4)) = gfs[s];
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                *reinterpret_cast<uint4*>(wimg + nimg * IMG + ql * 128 + (((2 * s + g) ^ rsw) << 4)) = __builtin_bit_cast(uint4, qf[s]);
+        }
+        __syncthreads();
+        float* pw = part + (size_t)blockIdx.x * NRP * ATT_HD;
+        for (int rb = wave; rb < NRP / 32; rb += NW) {
+            f32x16 acc[2] = {zero16(), zero16()};
+            for (int w2 = 0; w2 < NW; ++w2) {
+                if ((blk * NW + w2) * 32 >= L) break;         // that wave had no queries
+                const unsigned char* im = smem + w2 * (nimg + 1) * IMG;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const bf16x8 gt = trfrag(im + (rb >> 1) * IMG, la, rb & 1, ks);      // B: lane = r, slots = q
+#pragma unroll
+                    for (int db = 0; db < 2; ++db) acc[db] = mfma(trfrag(im + nimg * IMG, la, db, ks), gt, acc[db]);
+                }
+            }
+            float* prow = pw + (size_t)(rb * 32 + ql) * ATT_HD + 4 * g;                   // D: lane = r, registers = d
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg)
+                    *reinterpret_cast<float4*>(prow + db * 32 + 8 * rg) = make_float4(acc[db][rg * 4], acc[db][rg * 4 + 1], acc[db][rg * 4 + 2], acc[db][rg * 4 + 3]);
+        }
     }
     if constexpr (TR) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     coarse(63);
@@ -499,7 +555,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, ql = lane & 31;
     int blk, bh;
-    wg_coords(nblk, xcd_map, blk, bh);
+    wg_coords(nblk, xcd_map, blk, bh, (L / 32) / NW);
     const int b = bh / H, h = bh % H, D = H * ATT_HD;
     const bf16* qbase = qkv + (size_t)b * L * ldq + h * ATT_HD;
     const bf16* dobase = dout + (size_t)b * L * lddo + h * ATT_HD;
@@ -700,8 +756,12 @@ int64_t attn3_table_bytes(int Bn, int L, int H, int Hp, int Wp) {
     if (!attn3_ok(L, Hp, Wp)) return 0;
     return (int64_t)Bn * H * (L / 32) * a3::ttile_bytes(Hp);
 }
-static int a3_xcd_map_on() {
-    static const int v = [] { const char* e = getenv("PA_ATTN_XCD"); return e ? atoi(e) : 1; }();
+static int a3_xcd_map_on() {      // bit 0: XCD-contiguous head order (PA_ATTN_XCD=0 turns it off); bit 1: light workgroups last (PA_ATTN_LIGHT_LAST=0)
+    static const int v = [] {
+        const char* e = getenv("PA_ATTN_XCD");
+        const char* l = getenv("PA_ATTN_LIGHT_LAST");
+        return ((e ? atoi(e) : 1) ? 1 : 0) | ((l ? atoi(l) : 1) ? 2 : 0);
+    }();
     return v;
 }
 
@@ -721,11 +781,63 @@ int attn3_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t
     return (int)hipGetLastError();
 }
 
-int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const float* delta,
-              void* tables, bf16* dqkv, bf16* dG, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st) {
+// ---- fused rel-pos table gradient: one fp32 [NRP][64] partial per dQ workgroup, summed in a fixed order (two stages)
+namespace a3 {
+constexpr int RED_ZC = 32;
+__global__ __launch_bounds__(256) void relpos_part_reduce_kernel(const float4* __restrict__ part, float4* __restrict__ tmp, int n4, int nz) {
+    __shared__ float4 sh[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), zl = threadIdx.x >> 6;
+    const int z0 = (int)((int64_t)nz * blockIdx.y / gridDim.y), z1 = (int)((int64_t)nz * (blockIdx.y + 1) / gridDim.y);
+    float4 s = make_float4(0, 0, 0, 0);
+    if (c < n4) {
+#pragma unroll 4
+        for (int z = z0 + zl; z < z1; z += 4) {
+            const float4 v = part[(size_t)z * n4 + c];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sh[zl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (zl == 0 && c < n4) {
+        float4 t = sh[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 4; ++k) { const float4 v = sh[k][threadIdx.x]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        tmp[(size_t)blockIdx.y * n4 + c] = t;
+    }
+}
+}   // namespace a3
+extern "C" int pa_slab_reduce(const float* in, float* out, int64_t n, int nz, int64_t stride, int accumulate, hipStream_t st);
+static int a3_fuse_on() {
+    static const int v = [] { const char* e = getenv("PA_ATTN3_FUSE_RELPOS"); return e ? atoi(e) : 1; }();
+    return g_attn3_fuse == 1 ? 0 : (g_attn3_fuse == 2 ? 1 : v);
+}
+int64_t attn3_relpos_partials_bytes(int Bn, int L, int H, int Hp, int Wp) {
+    if (!a3_fuse_on() || !attn3_ok(L, Hp, Wp)) return 0;
+    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    if (NRP > 16 * a3::NSMAX) return 0;
+    const int nblk = (L / 32 + a3::NW - 1) / a3::NW;
+    return (int64_t)nblk * Bn * H * NRP * ATT_HD * sizeof(float);
+}
+// part: what attn3_bwd's dQ kernel wrote; tmp: RED_ZC * NRP * 64 floats of scratch; drcat f32 [NRP][64], overwritten
+int attn3_relpos_reduce(const float* part, float* drcat, float* tmp, int Bn, int L, int H, int Hp, int Wp, hipStream_t st) {
     using namespace a3;
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
     const int nblk = (L / 32 + NW - 1) / NW;
+    const int nz = nblk * Bn * H, n4 = NRP * ATT_HD / 4;
+    const int zc = nz < RED_ZC ? nz : RED_ZC;
+    PA_LAUNCH(relpos_part_reduce_kernel, dim3((n4 + 63) / 64, zc), dim3(256), 0, st, reinterpret_cast<const float4*>(part),
+              reinterpret_cast<float4*>(tmp), n4, nz);
+    if (int e = (int)hipGetLastError()) return e;
+    return pa_slab_reduce(tmp, drcat, (int64_t)n4 * 4, zc, (int64_t)n4 * 4, 0, st);
+}
+
+int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const float* delta,
+              void* tables, bf16* dqkv, bf16* dG, float* part, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st) {
+    using namespace a3;
+    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    const int nblk = (L / 32 + NW - 1) / NW;
+    if (part != nullptr && NRP > 16 * NSMAX) return (int)hipErrorInvalidValue;
+    if (part == nullptr && dG == nullptr) return (int)hipErrorInvalidValue;
     unsigned char* tb = reinterpret_cast<unsigned char*>(tables);
     int e;
     {
@@ -738,13 +850,19 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
     static const int dkv_w = [] { const char* v = getenv("PA_ATTN3_DKV_WAVES"); return v ? atoi(v) : 2; }();
     {
         static const size_t pad = [] { const char* v = getenv("PA_ATTN3_LDS_PAD"); return v ? (size_t)atoi(v) : (size_t)0; }();   // diagnostics: fewer workgroups per CU
-        const size_t smem = 2 * (size_t)STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG + (size_t)ATT_HD * (NRP * 2 + 16) + pad;
-        auto kern = g_attn_trace ? bwd_dq_kernel<2, true, true> : (dq_w == 3 ? bwd_dq_kernel<3, false> : bwd_dq_kernel<2, A3_NDL>);
-        static bool done2 = false, done3 = false, donet = false;
-        if ((e = set_smem(reinterpret_cast<const void*>(kern), g_attn_trace ? donet : (dq_w == 3 ? done3 : done2)))) return e;
+        size_t smem = 2 * (size_t)STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG + (size_t)ATT_HD * (NRP * 2 + 16) + pad;
+        const bool fuse = part != nullptr;
+        if (fuse) {                                             // the dG / Q images of the fused rel-pos contraction reuse the whole allocation
+            const size_t need = (size_t)NW * ((NRP + 63) / 64 + 1) * IMG;
+            if (smem < need) smem = need;
+        }
+        auto kern = fuse ? bwd_dq_kernel<2, A3_NDL, false, true>
+                         : (g_attn_trace ? bwd_dq_kernel<2, true, true> : (dq_w == 3 ? bwd_dq_kernel<3, false> : bwd_dq_kernel<2, A3_NDL>));
+        static bool done2 = false, done3 = false, donet = false, donef = false;
+        if ((e = set_smem(reinterpret_cast<const void*>(kern), fuse ? donef : (g_attn_trace ? donet : (dq_w == 3 ? done3 : done2))))) return e;
         const char* ablv = getenv("PA_ATTN3_DQ_ABL");           // diagnostics, read per launch
-        PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcatT, dout, (size_t)lddo, lse, tb, dqkv, dG, L, H, Hp,
-                  NRP, scale, nblk, a3_xcd_map_on(), ablv ? atoi(ablv) : 0);
+        PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcatT, dout, (size_t)lddo, lse, tb, dqkv, dG, part, L, H,
+                  Hp, NRP, scale, nblk, a3_xcd_map_on(), ablv ? atoi(ablv) : 0);
         if ((e = (int)hipGetLastError())) return e;
     }
     {

@@ -515,13 +515,20 @@ static int attn_bwd_t(const T* qkv, int64_t ldq, const T* rcat, const T* rcatT, 
 }
 
 // dqkv: T [batch*L, 3*heads*hd] (same layout as qkv); dG: T [batch*L, heads*NRP]; aux: pa_attn_bwd_aux_bytes scratch
+extern "C" int64_t pa_attn_bwd_relpos_partials_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp, int head_dim) {
+    if (dtype != PA_BF16 || head_dim != ATT_HD || L != Hp * Wp) return 0;
+    return attn3_relpos_partials_bytes(batch, L, heads, Hp, Wp);
+}
 extern "C" int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, const void* rcatT, const void* dout, int64_t lddo,
-                           const float* lse, const float* delta, void* dqkv, void* dG, void* aux, void* tables, int batch, int L,
-                           int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t st) {
+                           const float* lse, const float* delta, void* dqkv, void* dG, void* relpos_part, void* aux, void* tables,
+                           int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t st) {
     if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4 || (head_dim != 64 && head_dim != 80)) return (int)hipErrorInvalidValue;
-    if (dtype == PA_BF16 && head_dim == ATT_HD && tables != nullptr && attn3_ok(L, Hp, Wp))
+    if (dtype == PA_BF16 && head_dim == ATT_HD && tables != nullptr && attn3_ok(L, Hp, Wp)) {
+        if (relpos_part != nullptr && attn3_relpos_partials_bytes(batch, L, heads, Hp, Wp) == 0) return (int)hipErrorInvalidValue;
         return attn3_bwd((const bf16*)qkv, ldq, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, tables, (bf16*)dqkv, (bf16*)dG,
-                         batch, L, heads, Hp, Wp, scale, st);
+                         (float*)relpos_part, batch, L, heads, Hp, Wp, scale, st);
+    }
+    if (relpos_part != nullptr || dG == nullptr) return (int)hipErrorInvalidValue;      // only the generation-3 kernels fuse the rel-pos gradient
     if (dtype == PA_BF16 && head_dim == ATT_HD && attn2_ok(L, Hp, Wp))
         return attn2_bwd((const bf16*)qkv, ldq, (const bf16*)rcat, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, (bf16*)dqkv,
                          (bf16*)dG, aux, batch, L, heads, Hp, Wp, scale, st);
@@ -561,6 +568,11 @@ static int relpos_grad_t(const T* dG, const T* qkv, int64_t ldq, float* drcat, f
     int e = launch_gemm<T, 2, 2>(A, B, Epi{ws, (size_t)NRP * hd, NRP, hd}, NRP, hd, R, splits, H, st);
     if (e) return e;
     return pa_slab_reduce(ws, drcat, (int64_t)NRP * hd, splits * H, (int64_t)NRP * hd, 0, st);
+}
+extern "C" int pa_attn_bwd_relpos_reduce(const void* relpos_part, float* drcat, void* workspace, int batch, int L, int heads, int Hp, int Wp,
+                                         int head_dim, hipStream_t st) {
+    if (head_dim != ATT_HD || relpos_part == nullptr || attn3_relpos_partials_bytes(batch, L, heads, Hp, Wp) == 0) return (int)hipErrorInvalidValue;
+    return attn3_relpos_reduce((const float*)relpos_part, drcat, (float*)workspace, batch, L, heads, Hp, Wp, st);
 }
 extern "C" int pa_attn_bwd_relpos(int dtype, const void* dG, const void* qkv, int64_t ldq, float* drcat, void* workspace, int batch, int L,
                                   int heads, int Hp, int Wp, int head_dim, hipStream_t st) {

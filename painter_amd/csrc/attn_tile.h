@@ -24,13 +24,33 @@ typedef __attribute__((ext_vector_type(8))) float f32x8;
 // XCD has its own 4 MB L2: give every XCD a contiguous run of (head, row block) pairs, row block fastest, so that all row blocks
 // of a head stream the head's K/V (or Q/dO/aux) tiles through ONE L2 instead of eight (7-8 heads x 0.4 MB live per XCD).
 // PA_ATTN_XCD=0 (diagnostics) keeps the plain order.
-DEVI void wg_coords(int nblk, int xcd_map, int& blk, int& bh) {
+// xcd_map bit 1 (generation 3, "light last"): when L / 32 is not a multiple of the NW row blocks a workgroup takes, the last workgroup
+// of every head has idle waves (1568 tokens: 12 full workgroups + one with a single live wave, which still walks the whole key loop).
+// The full workgroups are numbered first -- 12 x 128 heads = 1536 = exactly three rounds of the 512 resident workgroups at the
+// ViT-L B = 8 shape -- and the light ones take the last block indices, i.e. they are dispatched last and share the final partial round
+// among themselves instead of holding a slot beside full workgroups.  Both sets keep the XCD-contiguous head order.
+DEVI int xcd_run(int n, int total) {
+    const int xq = total >> 3, xr = total & 7, xcd = n & 7;
+    return (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (n >> 3);
+}
+DEVI void wg_coords(int nblk, int xcd_map, int& blk, int& bh, int nfull = 0) {
     const int n = blockIdx.x, total = gridDim.x;
-    int v = n;
-    if (xcd_map) {
-        const int xq = total >> 3, xr = total & 7, xcd = n & 7;
-        v = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (n >> 3);
+    if ((xcd_map & 2) && nfull > 0 && nfull < nblk) {
+        const int nbh = total / nblk, heavy = nfull * nbh;
+        if (n < heavy) {
+            const int v = (xcd_map & 1) ? xcd_run(n, heavy) : n;
+            bh = v / nfull;
+            blk = v - bh * nfull;
+        } else {
+            // only nblk == nfull + 1 reaches here (one light workgroup per head)
+            const int m = n - heavy, per = nblk - nfull, lt = nbh * per;
+            const int v = (xcd_map & 1) ? xcd_run(m, lt) : m;
+            bh = v / per;
+            blk = nfull + (v - bh * per);
+        }
+        return;
     }
+    const int v = (xcd_map & 1) ? xcd_run(n, total) : n;
     bh = v / nblk;
     blk = v - bh * nblk;
 }

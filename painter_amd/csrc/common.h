@@ -117,6 +117,8 @@ DEVI float wave_max(float v) {
 // The engine asks for 4 when that GEMM runs on the side stream beside the data-gradient chain (fewer, longer workgroups: 54.54 -> 54.35
 // ms/step), the stand-alone optimum is 16.
 inline int g_relpos_splits = 0;
+// pa_debug_set(7, v): 0 = default (fused rel-pos table gradient in the generation-3 dQ kernel unless PA_ATTN3_FUSE_RELPOS=0), 1 = off, 2 = on
+inline int g_attn3_fuse = 0;
 
 // exact (erf) GELU and its derivative -- nn.GELU default (Painter/models_painter.py:253)
 DEVI float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

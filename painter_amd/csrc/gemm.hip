@@ -230,6 +230,35 @@ __global__ void slab_reduce_wide_kernel(const float* __restrict__ in, float* out
     }
     *reinterpret_cast<float4*>(out + i) = s;
 }
+// the same reduction with the column range split over two destinations: columns [0, n0) -> out0, [n0, n) -> out1 (LayerNorm backward:
+// [dgamma | dbeta] and the bias column sum from one set of partial rows)
+__global__ __launch_bounds__(256) void slab_reduce2_kernel(const float* __restrict__ in, float* out0, float* out1, size_t n0, size_t n, int nz, size_t stride) {
+    __shared__ float4 sh[16][17];
+    const int cg = threadIdx.x & 15, zl = threadIdx.x >> 4;
+    const size_t i = ((size_t)blockIdx.x * 16 + cg) * 4;
+    float4 s = make_float4(0, 0, 0, 0);
+    if (i < n) {
+#pragma unroll 4
+        for (int z = zl; z < nz; z += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(in + (size_t)z * stride + i);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+    }
+    sh[zl][cg] = s;
+    __syncthreads();
+    if (zl == 0 && i < n) {
+        float4 t = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const float4 v = sh[k][cg]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(i < n0 ? out0 + i : out1 + (i - n0)) = t;
+    }
+}
+int pa_slab_reduce2(const float* in, float* out0, float* out1, int64_t n0, int64_t n, int nz, int64_t stride, hipStream_t st) {
+    if (n <= 0) return 0;
+    if (n % 4 || n0 % 4 || stride % 4 || (n > n0 && out1 == nullptr)) return (int)hipErrorInvalidValue;
+    PA_LAUNCH(slab_reduce2_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, in, out0, out1, (size_t)n0, (size_t)n, nz, (size_t)stride);
+    LAUNCH_CHECK();
+}
 extern "C" int pa_slab_reduce(const float* in, float* out, int64_t n, int nz, int64_t stride, int accumulate, hipStream_t st) {
     if (n <= 0) return 0;
     if (n % 4 || stride % 4) return (int)hipErrorInvalidValue;
@@ -445,5 +474,6 @@ extern "C" int pa_debug_set(int which, int value) {
     if (which < 0 || which >= 8) return (int)hipErrorInvalidValue;
     g256::g_dbg[which] = value;
     if (which == 6) g_relpos_splits = value;
+    if (which == 7) g_attn3_fuse = value;
     return 0;
 }

@@ -62,21 +62,24 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx_out = (dres ? dres : 0) + LNbwd(dy);  optional T copy dxT = rowscale[row / rps] * dx_out;
-// per-workgroup partial dgamma / dbeta -> part[block][2][D]
-template <typename T, int NI>
+// per-workgroup partial dgamma / dbeta -> part[block][NP][D], NP = 2, or 3 with CS: the third row is the column sum of dxT AS STORED
+// (rounded to T) = the bias gradient of the nn.Linear whose dY this dxT is (fc2 / proj) -- it used to be a separate pass over dxT
+template <typename T, int NI, bool CS>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, size_t lddy, const float* __restrict__ x, size_t ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* dres, float* dx, size_t lddx,
                                                      T* dxT, size_t lddxT, const float* __restrict__ rowscale, int rps,
                                                      float* __restrict__ part, int R, int D) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float4 g[NI], ag[NI], ab[NI];
+    constexpr int NP = CS ? 3 : 2;
+    float4 g[NI], ag[NI], ab[NI], ac[CS ? NI : 1];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int c = lane * 4 + 256 * i;
         g[i] = (c < D) ? load4(gamma + c) : make_float4(0, 0, 0, 0);
         ag[i] = make_float4(0, 0, 0, 0);
         ab[i] = make_float4(0, 0, 0, 0);
+        if constexpr (CS) ac[i] = make_float4(0, 0, 0, 0);
     }
     for (int row = blockIdx.x * 4 + wave; row < R; row += gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
@@ -112,10 +115,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, s
                 }
                 *reinterpret_cast<float4*>(dx + (size_t)row * lddx + c) = o;
                 if (dxT) store4<T>(dxT + (size_t)row * lddxT + c, o.x * sc, o.y * sc, o.z * sc, o.w * sc);
+                if constexpr (CS) {          // what a column sum of dxT would read back: the values rounded to T
+                    ac[i].x += to_f(from_f<T>(o.x * sc)); ac[i].y += to_f(from_f<T>(o.y * sc));
+                    ac[i].z += to_f(from_f<T>(o.z * sc)); ac[i].w += to_f(from_f<T>(o.w * sc));
+                }
             }
         }
     }
-    // block reduce of the 4 waves' partial dgamma / dbeta
+    // block reduce of the 4 waves' partial sums, through [4][2][D] floats of LDS whatever NP is (the column sum goes through the same
+    // 32 KB in a second round: with [4][3][D] the kernel dropped from 4 to 3 resident workgroups per CU)
     extern __shared__ float red[];   // [4][2][D]
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -127,12 +135,26 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, s
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < 2 * D; idx += 256) {
-        const float s = red[idx] + red[2 * D + idx] + red[4 * D + idx] + red[6 * D + idx];
-        part[(size_t)blockIdx.x * 2 * D + idx] = s;
+        const float s = (red[idx] + red[2 * D + idx]) + (red[4 * D + idx] + red[6 * D + idx]);
+        part[(size_t)blockIdx.x * NP * D + idx] = s;
+    }
+    if constexpr (CS) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int c = lane * 4 + 256 * i;
+            if (c < D) *reinterpret_cast<float4*>(red + (size_t)wave * D + c) = ac[i];
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < D; idx += 256) {
+            const float s = (red[idx] + red[D + idx]) + (red[2 * D + idx] + red[3 * D + idx]);
+            part[(size_t)blockIdx.x * NP * D + 2 * D + idx] = s;
+        }
     }
 }
 
 extern "C" int pa_slab_reduce(const float* in, float* out, int64_t n, int nz, int64_t stride, int accumulate, hipStream_t st);
+int pa_slab_reduce2(const float* in, float* out0, float* out1, int64_t n0, int64_t n, int nz, int64_t stride, hipStream_t st);   // gemm.hip
 
 template <typename T>
 static int ln_fwd_t(const float* x, int64_t ldx, const float* g, const float* b, float eps, T* y, int64_t ldy, float* mean,
@@ -160,17 +182,21 @@ static int ln_bwd_blocks(int R) {
     int b = (R + 3) / 4;
     return b > 1024 ? 1024 : b;      // 4 waves per SIMD resident on 256 CUs
 }
-extern "C" int64_t pa_layernorm_bwd_workspace_bytes(int R, int D) { return (int64_t)ln_bwd_blocks(R) * 2 * D * sizeof(float); }
+extern "C" int64_t pa_layernorm_bwd_workspace_bytes(int R, int D) { return (int64_t)ln_bwd_blocks(R) * 3 * D * sizeof(float); }
 
 template <typename T>
 static int ln_bwd_t(const T* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean, const float* rstd,
                     const float* gamma, const float* dres, float* dx, int64_t lddx, T* dxT, int64_t lddxT,
-                    const float* rowscale, int rps, float* dgamma_dbeta, float* ws, int R, int D, hipStream_t st) {
+                    const float* rowscale, int rps, float* dgamma_dbeta, float* dxT_colsum, float* ws, int R, int D, hipStream_t st) {
     const int ni = (D + 255) / 256;
     const int nb = ln_bwd_blocks(R);
     dim3 grid(nb), blk(256);
-    const size_t sm = (size_t)8 * D * sizeof(float);
-#define LN_BWD(NI) PA_LAUNCH((ln_bwd_kernel<T, NI>), grid, blk, sm, st, dy, (size_t)lddy, x, (size_t)ldx, mean, rstd, gamma, dres, dx, (size_t)lddx, dxT, (size_t)lddxT, rowscale, rps, ws, R, D)
+    const bool cs = dxT_colsum != nullptr;
+    if (cs && dxT == nullptr) return (int)hipErrorInvalidValue;
+    const int np = cs ? 3 : 2;
+    const size_t sm = (size_t)8 * D * sizeof(float);          // <= 64 KB for every D the kernel takes (NI <= 8: D <= 2048)
+#define LN_BWD2(NI, CS_) PA_LAUNCH((ln_bwd_kernel<T, NI, CS_>), grid, blk, sm, st, dy, (size_t)lddy, x, (size_t)ldx, mean, rstd, gamma, dres, dx, (size_t)lddx, dxT, (size_t)lddxT, rowscale, rps, ws, R, D)
+#define LN_BWD(NI) do { if (cs) LN_BWD2(NI, true); else LN_BWD2(NI, false); } while (0)
     if (ni <= 1) LN_BWD(1);
     else if (ni <= 2) LN_BWD(2);
     else if (ni <= 4) LN_BWD(4);
@@ -178,19 +204,21 @@ static int ln_bwd_t(const T* dy, int64_t lddy, const float* x, int64_t ldx, cons
     else if (ni <= 8) LN_BWD(8);
     else return (int)hipErrorInvalidValue;
 #undef LN_BWD
+#undef LN_BWD2
     int e = (int)hipGetLastError();
     if (e) return e;
-    return pa_slab_reduce(ws, dgamma_dbeta, 2 * D, nb, 2 * D, 0, st);
+    // partial rows are [dgamma | dbeta (| colsum)]: one reduction launch writes the first 2 D sums to dgamma_dbeta and the rest to dxT_colsum
+    return pa_slab_reduce2(ws, dgamma_dbeta, dxT_colsum, 2 * D, np * D, nb, np * D, st);
 }
 // dgamma_dbeta: [2, D] fp32 (dgamma then dbeta), overwritten.
 extern "C" int pa_layernorm_bwd(int dtype, const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                                 const float* rstd, const float* gamma, const float* dres, float* dx, int64_t lddx,
                                 void* dxT, int64_t lddxT, const float* rowscale, int rows_per_sample,
-                                float* dgamma_dbeta, void* workspace, int R, int D, hipStream_t st) {
+                                float* dgamma_dbeta, float* dxT_colsum, void* workspace, int R, int D, hipStream_t st) {
     if (D % 4 || lddy % 4 || ldx % 4 || lddx % 4 || lddxT % 4) return (int)hipErrorInvalidValue;
     if (dtype == PA_BF16)
         return ln_bwd_t<bf16>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres, dx, lddx, (bf16*)dxT, lddxT, rowscale,
-                              rows_per_sample, dgamma_dbeta, (float*)workspace, R, D, st);
+                              rows_per_sample, dgamma_dbeta, dxT_colsum, (float*)workspace, R, D, st);
     return ln_bwd_t<float>((const float*)dy, lddy, x, ldx, mean, rstd, gamma, dres, dx, lddx, (float*)dxT, lddxT, rowscale,
-                           rows_per_sample, dgamma_dbeta, (float*)workspace, R, D, st);
+                           rows_per_sample, dgamma_dbeta, dxT_colsum, (float*)workspace, R, D, st);
 }

@@ -288,7 +288,8 @@ class HotPath:
             tag = "dec" if wname.startswith("decoder") else wname.split(".")[-2]
             if side is None or (filt is not None and tag not in filt):
                 G[wname] = ops.linear_wgrad(dy, x)
-                G[bname] = ops.colsum(dy, out=bout)
+                if bname not in G:                 # (fc2 / proj biases: already summed by the LayerNorm backward that produced dy)
+                    G[bname] = ops.colsum(dy, out=bout)
                 return
             if filt is not None and "nocolsum" in filt:
                 G[bname] = ops.colsum(dy, out=bout)
@@ -355,6 +356,21 @@ class HotPath:
         dnorm = None
         dx = None
         dyT_next = None
+        flats = {}
+
+        def block_flat(i_):
+            """The flat small-gradient buffer of block i_ (allocated on first use: block i_ + 1's norm1 backward already writes block
+            i_'s fc2 bias gradient into it)."""
+            if i_ not in flats:
+                nrp_, hd_ = rc_shape
+                sizes = [2 * D, 2 * D, 3 * D, D, c.hidden, D, nrp_ * hd_]
+                fb = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
+                if side is not None:
+                    fb.record_stream(side)
+                flats[i_] = (fb, dict(zip(("n1", "n2", "qkv", "proj", "fc1", "fc2", "rel"), torch.split(fb, sizes))))
+            return flats[i_]
+
+        rc_shape = tuple(S.blocks[-1][5].shape)            # Rcat [NRP, head_dim]: the same for every block
         for i in reversed(range(c.depth)):
             pre = "blocks.%d." % i
             x0, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc, atab = S.blocks[i]
@@ -364,19 +380,19 @@ class HotPath:
             # the block's small gradients (LayerNorm affine, the four biases, the rel-pos tables) live in ONE flat buffer so that the
             # gradient exchange sends them as one message without a flattening copy: [norm1 g,b | norm2 g,b | qkv.b | proj.b | fc1.b | fc2.b | d rcat]
             nrp, hd = rcat.shape
-            sizes = [2 * D, 2 * D, 3 * D, D, c.hidden, D, nrp * hd]
-            flat = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
-            if side is not None:
-                flat.record_stream(side)
-            fl = dict(zip(("n1", "n2", "qkv", "proj", "fc1", "fc2", "rel"), torch.split(flat, sizes)))
+            flat, fl = block_flat(i)
+            del flats[i]
             # dyT = bf16(ds_m * dx) is emitted by the kernel that produces the final dx of this block's output: the tap
             # LayerNorm backward, block i+1's norm1 backward (dyT_next), or the stream-merge backward
             if i in c.taps:
                 k = c.taps.index(i)
                 xt, mt, rt = S.taps[k]
                 dyT = torch.empty((R, D), dtype=T, device=dev)
+                # (the LayerNorm backward kernels also sum the columns of the dxT they emit: dxT is the dY of fc2 / proj, so that
+                # sum is the layer's bias gradient -- no separate pass over dxT)
                 dx, gb = ops.layernorm_bwd(dconcat[:, k * D:(k + 1) * D], xt, mt, rt, P["norm.weight"], dres=dx, dx=dx, dxT=dyT,
-                                           rowscale=ds_m, rows_per_sample=L)
+                                           rowscale=ds_m, rows_per_sample=L, dxT_colsum=fl["fc2"])
+                G[pre + "mlp.fc2.bias"] = fl["fc2"]
                 dnorm = gb if dnorm is None else _add_(dnorm, gb)
             elif i == c.merge_idx:
                 dx, dyT = ops.merge_bwd(T, dx, ds_m, L, B * L, D)
@@ -394,7 +410,8 @@ class HotPath:
             # dyT may still be read by the side stream: the attention branch's dY gets its own buffer
             dyA = torch.empty_like(dyT) if side is not None else dyT
             dx, gb = ops.layernorm_bwd(dln2, x1, mean2, rstd2, P[pre + "norm2.weight"], dres=dx, dx=dx, dxT=dyA,
-                                       rowscale=ds_a, rows_per_sample=L, gb=fl["n2"].view(2, D))
+                                       rowscale=ds_a, rows_per_sample=L, gb=fl["n2"].view(2, D), dxT_colsum=fl["proj"])
+            G[pre + "attn.proj.bias"] = fl["proj"]
             del dyT
             tr("%d.dx_ln2" % i, dx); tr("%d.dyA" % i, dyA); tr("%d.gb2" % i, gb)
             G[pre + "norm2.weight"], G[pre + "norm2.bias"] = gb[0], gb[1]
@@ -419,8 +436,13 @@ class HotPath:
             if nxt >= 0 and nxt not in c.taps and nxt != c.merge_idx:
                 dyT_next = torch.empty((R, D), dtype=T, device=dev)
             ds_next = None if (S.drop is None or nxt < 0) else S.drop[nxt][1]
+            cs_next = None
+            if dyT_next is not None:               # dyT_next is block nxt's fc2 dY: its column sum goes into block nxt's flat buffer
+                cs_next = block_flat(nxt)[1]["fc2"]
+                G["blocks.%d.mlp.fc2.bias" % nxt] = cs_next
             dx, gb = ops.layernorm_bwd(dln1, x0, mean1, rstd1, P[pre + "norm1.weight"], dres=dx, dx=dx, dxT=dyT_next,
-                                       rowscale=ds_next if dyT_next is not None else None, rows_per_sample=L, gb=fl["n1"].view(2, D))
+                                       rowscale=ds_next if dyT_next is not None else None, rows_per_sample=L, gb=fl["n1"].view(2, D),
+                                       dxT_colsum=cs_next)
             G[pre + "norm1.weight"], G[pre + "norm1.bias"] = gb[0], gb[1]
             tr("%d.dx_ln1" % i, dx)
             del x0, ln1, qkv, ao, x1, ln2, hpre, act, atab

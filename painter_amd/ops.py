@@ -126,8 +126,10 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype, out=None):
     return out, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, dx=None, dxT=None, rowscale=None, rows_per_sample=1, gb=None):
-    """-> dx (f32, = dres + LN'(dy)), dgamma_dbeta [2, D] (written into `gb` when given)."""
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, dx=None, dxT=None, rowscale=None, rows_per_sample=1, gb=None, dxT_colsum=None):
+    """-> dx (f32, = dres + LN'(dy)), dgamma_dbeta [2, D] (written into `gb` when given).
+    dxT_colsum (f32 [D], optional, needs dxT): receives the column sums of dxT as stored -- the bias gradient of the nn.Linear whose dY
+    dxT is -- from the same pass."""
     R, D = x.shape
     if dx is None:
         dx = torch.empty((R, D), dtype=torch.float32, device=x.device)
@@ -135,9 +137,11 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, dx=None, dxT=None, rowsca
         gb = torch.empty((2, D), dtype=torch.float32, device=x.device)
     assert gb.shape == (2, D) and gb.is_contiguous() and gb.dtype == torch.float32
     ws = workspace(lib.pa_layernorm_bwd_workspace_bytes(R, D), x.device)
+    if dxT_colsum is not None:
+        assert dxT is not None and dxT_colsum.shape == (D,) and dxT_colsum.dtype == torch.float32 and dxT_colsum.is_contiguous()
     check(lib.pa_layernorm_bwd(code(dy.dtype), p(dy), dy.stride(0), p(x), x.stride(0), p(mean), p(rstd), p(gamma),
                                p(dres), p(dx), dx.stride(0), p(dxT), 0 if dxT is None else dxT.stride(0), p(rowscale),
-                               rows_per_sample, p(gb), p(ws), R, D, stream()), "pa_layernorm_bwd")
+                               rows_per_sample, p(gb), p(dxT_colsum), p(ws), R, D, stream()), "pa_layernorm_bwd")
     return dx, gb
 
 
@@ -179,7 +183,9 @@ def relpos_pack_t(rel_pos_h, rel_pos_w, Hp, Wp, dtype):
 
 
 def attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale, tables=None):
-    """-> (dqkv T [batch*L, 3*heads*hd], dG T [batch*L, heads*NRP]): the data gradients and the per-query bias gradients.
+    """-> (dqkv T [batch*L, 3*heads*hd], dG): the data gradients and what attn_bwd_relpos() turns into the rel-pos table gradients --
+    either the per-query bias gradients dG T [batch*L, heads*NRP], or (28-token-wide bf16 kernels with `tables`) the per-workgroup
+    fp32 partial sums of the table gradient itself, a uint8 scratch tensor (the dQ kernel contracts them; dG never exists).
     tables: what attn_fwd(need_tables=True) returned (the backward writes its lse / delta fields into it)."""
     T = qkv.dtype
     dev = qkv.device
@@ -188,20 +194,29 @@ def attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, sca
     check(lib.pa_attn_bwd_delta(code(T), p(out), out.stride(0), p(dout), dout.stride(0), p(delta), batch, L, heads, hd,
                                 stream()), "pa_attn_bwd_delta")
     dqkv = torch.empty_like(qkv)
-    dG = torch.empty((batch * L, heads * nrp), dtype=T, device=dev)
+    nb = lib.pa_attn_bwd_relpos_partials_bytes(code(T), batch, L, heads, Hp, Wp, hd) if tables is not None else 0
+    dG = part = None
+    if nb > 0:
+        part = torch.empty((nb,), dtype=torch.uint8, device=dev)
+    else:
+        dG = torch.empty((batch * L, heads * nrp), dtype=T, device=dev)
     aux = workspace(lib.pa_attn_bwd_aux_bytes(batch, L, heads, Hp, Wp), dev, slot=1)
     check(lib.pa_attn_bwd(code(T), p(qkv), qkv.stride(0), p(rcat), p(rcatT), p(dout), dout.stride(0), p(lse), p(delta),
-                          p(dqkv), p(dG), p(aux), p(tables), batch, L, heads, Hp, Wp, hd, float(scale), stream()), "pa_attn_bwd")
-    return dqkv, dG
+                          p(dqkv), p(dG), p(part), p(aux), p(tables), batch, L, heads, Hp, Wp, hd, float(scale), stream()), "pa_attn_bwd")
+    return dqkv, (dG if part is None else part)
 
 
 def attn_bwd_relpos(dG, qkv, nrp, batch, L, heads, Hp, Wp, out=None):
-    """-> drcat f32 [NRP, hd] = d[rel_pos_h ; rel_pos_w ; pad]: a parameter gradient (nothing downstream consumes it)."""
+    """-> drcat f32 [NRP, hd] = d[rel_pos_h ; rel_pos_w ; pad]: a parameter gradient (nothing downstream consumes it).
+    dG: the second result of attn_bwd_core (per-query bias gradients -> gather GEMM; uint8 partials -> fixed-order sum)."""
     T = qkv.dtype
     hd = qkv.shape[1] // (3 * heads)
     drcat = out if out is not None else torch.empty((nrp, hd), dtype=torch.float32, device=qkv.device)
     assert drcat.shape == (nrp, hd) and drcat.is_contiguous()
     ws = workspace(lib.pa_attn_bwd_relpos_workspace_bytes(code(T), batch, L, heads, Hp, Wp, hd), qkv.device)
+    if dG.dtype == torch.uint8:
+        check(lib.pa_attn_bwd_relpos_reduce(p(dG), p(drcat), p(ws), batch, L, heads, Hp, Wp, hd, stream()), "pa_attn_bwd_relpos_reduce")
+        return drcat
     check(lib.pa_attn_bwd_relpos(code(T), p(dG), p(qkv), qkv.stride(0), p(drcat), p(ws), batch, L, heads, Hp, Wp, hd,
                                  stream()), "pa_attn_bwd_relpos")
     return drcat

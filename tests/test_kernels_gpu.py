@@ -183,7 +183,12 @@ def test_layernorm_fwd_bwd(T, R, D):
     rps = 8
     rowscale = gen(((R + rps - 1) // rps,), 6).abs() + 0.5
     dxT = torch.empty((R, D), dtype=T, device=DEV)
-    dx, gb = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres=dres, dxT=dxT, rowscale=rowscale, rows_per_sample=rps)
+    cs = torch.empty((D,), device=DEV)
+    dx, gb = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres=dres, dxT=dxT, rowscale=rowscale, rows_per_sample=rps, dxT_colsum=cs)
+    # the fused bias gradient: column sums of dxT AS STORED (the same values a separate pa_colsum pass over dxT reads)
+    assert relerr(cs, dxT.double().sum(0)) < 1e-5 and relerr(cs, ops.colsum(dxT)) < 1e-5
+    dx_plain, gb_plain = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres=dres, dxT=torch.empty_like(dxT), rowscale=rowscale, rows_per_sample=rps)
+    assert torch.equal(dx, dx_plain) and torch.equal(gb, gb_plain)            # the extra output changes nothing else
     ref = dres.double() + xr.grad
     assert relerr(dx, ref) < 2e-5
     assert relerr(dxT.float(), ref * rowscale.repeat_interleave(rps)[:R, None].double()) < TOL[T]
@@ -406,6 +411,44 @@ def test_attn_generations_agree(attn_generation):
     # 0 (default) and 3 (explicit) select the same generation-3 kernels: bit-identical
     for a, b in zip(res[0], res[3]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("B,H,Hp,Wp", [(2, 2, 56, 28), (1, 3, 16, 28), (1, 1, 8, 28)])
+def test_attn3_fused_relpos_gradient_vs_dG_gemm(B, H, Hp, Wp):
+    """The rel-pos table gradient contracted inside the generation-3 dQ kernel (one fp32 partial per workgroup, fixed-order sum; no dG
+    in HBM) against the older route -- dG written as bf16, gather GEMM over it -- on the same inputs: both contract the same bf16 dG
+    entries with the same bf16 Q, so they agree to fp32 summation order; dQ / dK / dV must be bit-identical (the key loop is shared).
+    Both against the fp64 reference too, and the fused route twice for bit-stability."""
+    from painter_amd._lib import PA_BF16, lib
+    L, qkv, rcat, rcatT, dout = _attn3_inputs(B, H, Hp, Wp)
+    nh, nw = 2 * Hp - 1, 2 * Wp - 1
+    out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
+    res = {}
+    try:
+        for mode in (2, 1, 2):
+            assert lib.pa_debug_set(7, mode) == 0
+            nb = lib.pa_attn_bwd_relpos_partials_bytes(PA_BF16, B, L, H, Hp, Wp, 64)
+            assert (nb > 0) == (mode == 2)
+            dqkv, dg = ops.attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables)
+            assert (dg.dtype == torch.uint8) == (mode == 2)
+            drcat = ops.attn_bwd_relpos(dg, qkv, rcat.shape[0], B, L, H, Hp, Wp)
+            if mode in res:
+                assert torch.equal(res[mode][0], dqkv) and torch.equal(res[mode][1], drcat)
+            res[mode] = (dqkv.clone(), drcat.clone())
+    finally:
+        lib.pa_debug_set(7, 0)
+    assert torch.equal(res[1][0], res[2][0])
+    assert relerr(res[2][1], res[1][1]) < 1e-5, relerr(res[2][1], res[1][1])
+    q64 = qkv.double().clone().requires_grad_(True)
+    rh64 = rcat[:nh].double().clone().requires_grad_(True)
+    rw64 = rcat[nh:nh + nw].double().clone().requires_grad_(True)
+    ref, _ = attn_reference(q64, rh64, rw64, B, L, H, Hp, Wp, 0.125)
+    ref.backward(dout.double())
+    for mode in (1, 2):
+        e = (relerr(res[mode][1][:nh], rh64.grad), relerr(res[mode][1][nh:nh + nw], rw64.grad))
+        print("rel-pos table gradient vs fp64, mode %d (1 = dG + GEMM, 2 = fused): %.3e %.3e" % ((mode,) + e))
+        assert max(e) < 1.6e-2
+    assert float(res[2][1][nh + nw:].abs().max()) == 0.0
 
 
 @pytest.mark.parametrize("gen_", [0])
