@@ -22,8 +22,12 @@ all-reduce (RCCL, bucketed, overlapped with backward) is inside the step.  Print
                  (profiles/roofline_traffic.json, tools/pmc_traffic.py) or null.
   sustained    = a second timed region right after the first: the same step repeated until --min-seconds (default 5 s) have elapsed
                  -- clocks and temperatures at steady state; `value` stays the contract's EXACTLY-K-steps number.
-  cpu_baseline = the CPU oracle (oracle/painter_oracle.py = the reference's forward restated op for op in PyTorch-CPU, kind "port":
-                 /root/reference does not exist on the GPU box) on the host cores, B = 1, fp32, thread count swept over {16, 32, 64, all
+  extra        = sclk_mhz_mean / power_w_mean: shader clock and board power sampled (amdgpu hwmon, 100 ms) during the sustained region --
+                 the step runs clock-managed (~2.0 GHz), so two boxes' lines are comparable only with these; the
+                 roofline peak stays the contract's 2500 TFLOP/s.
+  cpu_baseline = the unmodified reference class (kind "reference": Painter/models_painter.py through oracle/ref_import.py -- from
+                 /root/reference, or on the GPU box from the subset oracle/stage_ref.py staged at build time; kind "port" = the restated
+                 oracle/painter_oracle.py when neither exists) on the host cores, B = 1, fp32, thread count swept over {16, 32, 64, all
                  physical cores}: value = train forward+backward images/sec at the best count, the all-cores figure beside it.
 """
 import argparse
@@ -155,6 +159,7 @@ def cpu_baseline(budget_s=100.0):
     import statistics
 
     from oracle import painter_oracle as O
+    from oracle import ref_import
     logical = os.cpu_count()
     try:
         import psutil
@@ -163,18 +168,39 @@ def cpu_baseline(budget_s=100.0):
         phys = logical
     phys = min(logical, phys)                      # one thread per physical core at most: SMT siblings only add contention at B = 1
     cfg = O.vit_large_config()
-    P = {k: v.requires_grad_(True) for k, v in O.random_params(cfg, 1).items()}
     imgs, tgts, mask, valid = O.synthetic_batch(cfg, 1, 1234, "half")
+    kind = "port"
+    if ref_import.reference_available():
+        # the UNMODIFIED reference class (Painter/models_painter.py:464-472 through its own factory :476-487; from /root/reference, or on
+        # the GPU box from the subset oracle/stage_ref.py staged at build time), random parameters as in the port
+        ref = ref_import.load_reference_painter()
+        rmodel = ref.painter_vit_large_patch16_input896x448_win_dec64_8glb_sl1()
+        rmodel.load_state_dict(O.random_params(cfg, 1), strict=True)
+        rmodel.train()                                 # train mode as in the timed GPU step (DropPath 0.1 through the timm 0.3.2 stand-in)
+        kind = "reference"
 
-    def fwd_eval():
-        with torch.no_grad():
-            O.forward(P, cfg, imgs, tgts, mask, valid.clone())
+        def fwd_eval():
+            rmodel.eval()
+            with torch.no_grad():
+                rmodel(imgs, tgts, mask, valid.clone())
+            rmodel.train()
 
-    def fwd_bwd():
-        for v in P.values():
-            v.grad = None
-        loss, _, _ = O.forward(P, cfg, imgs, tgts, mask, valid.clone())
-        loss.backward()
+        def fwd_bwd():
+            rmodel.zero_grad(set_to_none=True)
+            loss, _, _ = rmodel(imgs, tgts, mask, valid.clone())
+            loss.backward()
+    else:
+        P = {k: v.requires_grad_(True) for k, v in O.random_params(cfg, 1).items()}
+
+        def fwd_eval():
+            with torch.no_grad():
+                O.forward(P, cfg, imgs, tgts, mask, valid.clone())
+
+        def fwd_bwd():
+            for v in P.values():
+                v.grad = None
+            loss, _, _ = O.forward(P, cfg, imgs, tgts, mask, valid.clone())
+            loss.backward()
 
     def once(fn):
         t0 = time.time()
@@ -199,10 +225,11 @@ def cpu_baseline(budget_s=100.0):
         tes.append(once(fwd_eval))
     te = statistics.median(tes)
     return {"value": round(1.0 / tt, 5), "unit": "images/sec", "cores": best, "logical_cpus": logical, "physical_cores": phys,
-            "kind": "port", "eval_forward_images_per_sec": round(1.0 / te, 5),
+            "kind": kind, "eval_forward_images_per_sec": round(1.0 / te, 5),
             "all_cores_value": round(1.0 / sweep[phys][0], 5),
             "thread_sweep_fwd_bwd_seconds": {str(n): [round(t, 2) for t in ts] for n, ts in sweep.items()},
-            "sample": "oracle/painter_oracle.py (the reference forward restated op for op, PyTorch-CPU fp32), ViT-L 896x448, B=1; warm-up "
+            "sample": ("the unmodified reference Painter.forward (models_painter.py:464-472, via oracle/ref_import.py), PyTorch-CPU fp32" if kind == "reference"
+                       else "oracle/painter_oracle.py (the reference forward restated op for op, PyTorch-CPU fp32)") + ", ViT-L 896x448, B=1; warm-up "
                       "forward+backward %.1f s, then one timed forward+backward per thread count %s, the best count (%d threads) re-timed "
                       "%s s, eval forward there %s s; value = 1 / median forward+backward at %d threads; all %d physical cores: %.5f images/s"
                       % (warm, counts, best, ["%.2f" % t for t in sweep[best]], ["%.2f" % t for t in tes], best, phys, 1.0 / sweep[phys][0])}
@@ -243,6 +270,75 @@ def optimizer_step_ms(model, step_fn):
     return res
 
 
+class ClockPowerSampler:
+    """Shader clock and board power from the amdgpu hwmon nodes, sampled every 100 ms on a thread (host-side file reads: nothing is
+    added to the GPU's queues).  A box may expose nodes of GPUs that are not ours: the node with the highest mean power under load is
+    reported."""
+
+    def __init__(self):
+        import glob
+        self.nodes = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"))
+        self.samples, self.on, self.alive = [], False, True
+
+    @staticmethod
+    def _read(path):
+        try:
+            return float(open(path).read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def _loop(self):
+        while self.alive:
+            if self.on:
+                row = {}
+                for n in self.nodes:
+                    pw = self._read(os.path.join(n, "power1_average"))
+                    if pw is None:
+                        pw = self._read(os.path.join(n, "power1_input"))
+                    row[n] = (pw, self._read(os.path.join(n, "freq1_input")))
+                self.samples.append(row)
+            time.sleep(0.1)
+
+    def start(self):
+        import threading
+        if self.nodes:
+            threading.Thread(target=self._loop, daemon=True).start()
+        self.on = True
+
+    def stop(self):
+        self.on, self.alive = False, False
+        best = None
+        for n in self.nodes:
+            pw = [r[n][0] for r in self.samples if r[n][0] is not None]
+            ck = [r[n][1] for r in self.samples if r[n][1] is not None]
+            if pw and (best is None or sum(pw) / len(pw) > best[0]):
+                best = (sum(pw) / len(pw), (sum(ck) / len(ck)) if ck else None)
+        if best is None:
+            return {"sclk_mhz_mean": None, "power_w_mean": None, "samples": len(self.samples)}
+        return {"sclk_mhz_mean": None if best[1] is None else round(best[1] / 1e6, 1), "power_w_mean": round(best[0] / 1e6, 1),
+                "samples": len(self.samples), "source": "amdgpu hwmon (freq1_input, power1_average), 100 ms, during the sustained region"}
+
+
+def _git_head():
+    """PAINTER_AMD_GIT_HEAD, else `git rev-parse` (build container), else what painter_amd/build.py recorded beside the library (the GPU
+    box's snapshot has no .git)."""
+    h = os.environ.get("PAINTER_AMD_GIT_HEAD")
+    if h and h != "unknown":
+        return h
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            dirty = subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True, timeout=10)
+            return r.stdout.strip() + ("-dirty" if dirty.stdout.strip() else "")
+    except Exception:
+        pass
+    try:
+        info = json.load(open(os.path.join(ROOT, "painter_amd", "lib", "build_info.json")))
+        return "%s (recorded at build time)" % info["git_head"]
+    except Exception:
+        return None
+
+
 def _lib_sha16():
     import hashlib
     from painter_amd._lib import LIB_PATH
@@ -263,10 +359,13 @@ def _free_port():
 def relaunch_under_launcher(args):
     """--gpus N > 1 without a launcher: start N ranks ourselves (one per GPU, RCCL) and hand back their exit code."""
     n_dev = torch.cuda.device_count()
-    if n_dev < args.gpus:
+    if n_dev < args.gpus and args.backend != "gloo":
         raise SystemExit("bench.py: --gpus %d asked for, %d visible -- refusing to print a line for fewer GPUs" % (args.gpus, n_dev))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # RCCL's ring kernels share the CUs with the backward: a stand-in with a ring step's traffic hides under the backward at +2-2.5 % on
+    # >= 32 workgroups and can no longer finish inside it on <= 16 (profiles/r03_gradsync_overlap_one_gpu.log) -- keep RCCL on the safe side
+    env.setdefault("NCCL_MIN_NCHANNELS", "32")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -285,17 +384,25 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--eval", action="store_true", help="eval mode (no DropPath)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo = DEBUG: run the N > 1 branch (relaunch, parameter broadcast, GradSync inside the backward, MAX-reduced timing) "
+                         "with the ranks sharing however many GPUs are visible (RCCL refuses two ranks per device); the line says so")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(relaunch_under_launcher(args))
 
     from painter_amd import models_painter, ops, parallel
-    rank, local, world = parallel.init_distributed()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("NCCL_MIN_NCHANNELS", "32")      # started by an external launcher: same floor as relaunch_under_launcher()
+    rank, local, world = parallel.init_distributed(backend=args.backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (the hot path has no CPU fallback)")
+    n_dev = torch.cuda.device_count()
+    if args.backend == "gloo":
+        local = local % n_dev                                   # debug arrangement: ranks share the visible devices
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
     distributed = world > 1 or parallel._SELFTEST
@@ -351,15 +458,21 @@ def main():
     # ---- sustained region: the same step until --min-seconds have gone by (every rank runs the same number of steps, fixed
     # beforehand from the first region's pace, so the collectives stay matched); `value` above stays the exactly-K-steps number
     sustained = None
+    clock_power = None
     if args.min_seconds > 0:
         n_sus = max(args.steps, int(args.min_seconds / (dt / args.steps)) + 1)
+        sampler = ClockPowerSampler() if rank == 0 else None
         barrier()
+        if sampler is not None:
+            sampler.start()
         t0 = time.perf_counter()
         for _ in range(n_sus):
             step()
         torch.cuda.synchronize()
         barrier()
         dts = time.perf_counter() - t0
+        if sampler is not None:
+            clock_power = sampler.stop()
         if distributed:
             t = torch.tensor([dts], device=dev, dtype=torch.float64)
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -369,9 +482,16 @@ def main():
 
     # ---- separate profiled pass (never compare a profiled arm with an un-profiled one: `value` above is un-instrumented)
     kernels = {}
+    launch_check = None
     if args.profile_steps > 0 and not distributed:          # single rank only: the extra steps would need every rank's all-reduce
+        from painter_amd._lib import lib as _lib
         side = model._hot.use_side_stream
         model._hot.use_side_stream = False                  # one stream: an event pair brackets exactly its own kernels
+        # ... and the parameter-gradient kernels get the sizing they have when they own the chip (the engine sizes them for HALF the chip
+        # because they normally run beside the data-gradient chain: timed alone at that size they looked 30 % slower than the
+        # one-stream rocprof summary under profiles/, which is taken with PAINTER_AMD_SIDE_STREAM=0, i.e. full-chip sizing)
+        _lib.pa_debug_set(3, 0)
+        _lib.pa_debug_set(6, 0)
         step()
         timer.active = True
         for _ in range(args.profile_steps):
@@ -379,6 +499,10 @@ def main():
         torch.cuda.synchronize()
         timer.active = False
         model._hot.use_side_stream = side
+        if side:
+            from painter_amd import engine as _engine
+            _lib.pa_debug_set(3, _engine.WGRAD_SIDE_TARGET)
+            _lib.pa_debug_set(6, _engine.RELPOS_SIDE_SPLITS)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         kernels = timer.results(peak)
         for v in kernels.values():
@@ -388,8 +512,11 @@ def main():
         want = (4 * len(model.blocks) + 1) * args.profile_steps
         # (+ the patch-embed weight gradient where the bf16 im2col fast path is on: it is an ordinary nn.Linear weight gradient there)
         extra_w = args.profile_steps if ops.patch_cols_ok(model.compute_dtype, args.batch, cfg.L, cfg.P, cfg.D) else 0
-        for fam, w_ in (("gemm256_fwd", want), ("gemm256_dgrad", want), ("gemm256_wgrad", want + extra_w)):
-            assert kernels[fam]["launches"] == w_, (fam, kernels[fam]["launches"], w_)
+        launch_check = {fam: {"launches": kernels.get(fam, {}).get("launches", 0), "expected": w_}
+                        for fam, w_ in (("gemm256_fwd", want), ("gemm256_dgrad", want), ("gemm256_wgrad", want + extra_w))}
+        bad = {f: v for f, v in launch_check.items() if v["launches"] != v["expected"]}
+        if bad:                                             # recorded, not fatal: the headline number above is already measured
+            print("bench.py: unexpected launch counts in the profiled pass: %s" % bad, file=sys.stderr)
 
     if rank == 0:
         ips = n_ranks * args.batch * args.steps / dt
@@ -399,13 +526,20 @@ def main():
             dk = max(kernels, key=lambda k: kernels[k]["kernel_ms_total"])
             dominant = dict(kernels[dk], family=dk)
         traffic = None
+        traffic_meta = None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")      # PMC passes (tools/pmc_traffic.py), bytes per launch
         if os.path.exists(tpath) and dominant is not None and args.model == "vit_large":
             try:
                 tj = json.load(open(tpath))
                 key = {"gemm256_fwd": "fc1", "gemm256_wgrad": "wgrad", "gemm256_dgrad": "dgrad", "attention_fwd": "attn_fwd",
                        "attention_bwd": "attn_bwd_dq"}.get(dominant["family"])
-                traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                meta = tj.get("_meta", {})
+                if meta.get("lib_sha16") == _lib_sha16():    # the PMC passes were taken on THIS library; anything else is refused
+                    traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+                    traffic_meta = meta
+                else:
+                    traffic_meta = {"refused": "profiles/roofline_traffic.json was measured on library %s, this run loads %s"
+                                               % (meta.get("lib_sha16"), _lib_sha16())}
             except Exception:
                 traffic = None
         achieved = ips / n_ranks * spec["blocks"] / 1e12
@@ -417,18 +551,22 @@ def main():
             "config": {"workload": spec["workload"] % (args.dtype, args.batch, n_ranks),
                        "global_batch": n_ranks * args.batch, "image": "896x448x3 stitched pair", "tokens": cfg.L,
                        "mode": "eval" if args.eval else "train (DropPath 0.1)", "parallelism": "dp%d" % n_ranks,
-                       "rccl_ranks": n_ranks if distributed else 0,
+                       "rccl_ranks": n_ranks if (distributed and args.backend == "nccl") else 0,
+                       "backend": (args.backend if args.backend == "nccl" else "gloo -- DEBUG arrangement: %d ranks on %d visible GPU(s); not a scaling number" % (n_ranks, n_dev)) if distributed else "n/a",
+                       "taps": list(cfg.taps),
                        "grad_allreduce": "RCCL bucketed, overlapped with backward" if n_ranks > 1 else "n/a"},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "definition": "images/s/GPU x %.3f TFLOP (attention + MLP blocks, fwd+bwd; SURVEY.md 8d) / dense bf16 MFMA peak" % (spec["blocks"] / 1e12),
                          "whole_model_achieved": round(ips / n_ranks * spec["whole"] / 1e12, 2),
                          "whole_model_frac": round(ips / n_ranks * spec["whole"] / 1e12 / peak, 4),
-                         "traffic": traffic, "traffic_source": "profiles/roofline_traffic.json (rocprofv3 PMC passes of this bench, tools/pmc_traffic.py; not re-measured inside this run)" if traffic is not None else None,
+                         "traffic": traffic, "traffic_source": "profiles/roofline_traffic.json (rocprofv3 PMC passes of this bench on this library, tools/pmc_traffic.py; not re-measured inside this run)" if traffic is not None else None,
+                         "traffic_meta": traffic_meta, "launch_count_check": launch_check,
                          "dominant_kernel": dominant, "kernels": kernels,
-                         "profiled_pass": "separate pass of %d steps after the timed region, HIP events per launch, one stream" % args.profile_steps},
+                         "profiled_pass": "separate pass of %d steps after the timed region, HIP events per launch, one stream, parameter-gradient kernels sized for the whole chip (as in profiles/*one_stream_kernel_stats.csv)" % args.profile_steps},
             "loss": round(lossv, 6),
             "sustained": sustained,
-            "build": {"git_head": os.environ.get("PAINTER_AMD_GIT_HEAD"), "lib_sha16": _lib_sha16()},
+            "extra": clock_power,
+            "build": {"git_head": _git_head(), "lib_sha16": _lib_sha16()},
         }
         if n_ranks == 1 and args.dtype == "bf16" and not args.no_optimizer and args.model == "vit_large":
             out["optimizer_step"] = optimizer_step_ms(model, step)

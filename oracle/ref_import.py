@@ -7,8 +7,9 @@ injecting minimal stand-ins for the third-party packages that are absent from th
 tests/golden/make_golden.py to generate the committed golden vectors and by the CPU tests that
 pin oracle/painter_oracle.py against the real reference when /root/reference is mounted.
 
-/root/reference does NOT exist on the GPU box: nothing under `-m gpu`, smoke() or bench.py may
-import this module.  Product code (painter_amd/) never imports anything from oracle/.
+/root/reference does NOT exist on the GPU box.  There the loader falls back to oracle/_ref/reference_subset.tar.gz: byte-for-byte
+copies of the few reference files the drivers need, staged by oracle/stage_ref.py at build time (git-ignored, so they never enter this
+repository; the gpurun snapshot carries the archive like the built .so files) and unpacked into a temporary directory on first use.  Product code (painter_amd/) never imports anything from oracle/.
 
 Stub semantics (timm 0.3.2, pinned at Painter/requirements.txt:1, asserted main_train.py:24):
   * Mlp       = fc1 -> act_layer() -> Dropout(drop) -> fc2 -> Dropout(drop)
@@ -26,7 +27,17 @@ import types
 import torch
 import torch.nn as nn
 
-REFERENCE_ROOT = os.environ.get("PAINTER_REFERENCE_ROOT", "/root/reference")
+def _reference_root():
+    env = os.environ.get("PAINTER_REFERENCE_ROOT")
+    if env:
+        return env
+    if os.path.isfile("/root/reference/Painter/models_painter.py"):
+        return "/root/reference"
+    from oracle import stage_ref                                                  # staged copies (oracle/stage_ref.py), unpacked to a temp dir
+    return stage_ref.unpack() or "/root/reference"
+
+
+REFERENCE_ROOT = _reference_root()
 PAINTER_DIR = os.path.join(REFERENCE_ROOT, "Painter")
 SEGGPT_DIR = os.path.join(REFERENCE_ROOT, "SegGPT", "SegGPT_inference")
 

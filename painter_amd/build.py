@@ -82,7 +82,27 @@ def build(force=False, verbose=True):
             print("built", LIB)
     elif verbose:
         print("up to date", LIB)
+    _record_build_info()
     return LIB
+
+
+def _record_build_info():
+    """painter_amd/lib/build_info.json: the git head this tree was built at and a digest of the kernel sources.  The snapshot that goes to
+    the GPU box has no .git; bench.py reads this file there to identify the build in its JSON line (refreshed on every build() call)."""
+    import json
+    root = os.path.dirname(HERE)
+    head = None
+    try:
+        r = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            d = subprocess.run(["git", "-C", root, "status", "--porcelain", "--untracked-files=no"], capture_output=True, text=True, timeout=10)
+            head = r.stdout.strip() + ("-dirty" if d.stdout.strip() else "")
+    except Exception:
+        pass
+    if head is None:
+        return                                   # no git here (the GPU box): keep what the build container recorded
+    with open(os.path.join(HERE, "lib", "build_info.json"), "w") as f:
+        json.dump({"git_head": head, "source_digest": _digest(sources() + headers())[:16]}, f)
 
 
 if __name__ == "__main__":

@@ -762,6 +762,8 @@ static int a3_xcd_map_on() {      // bit 0: XCD-contiguous head order (PA_ATTN_X
         const char* l = getenv("PA_ATTN_LIGHT_LAST");
         return ((e ? atoi(e) : 1) ? 1 : 0) | ((l ? atoi(l) : 1) ? 2 : 0);
     }();
+    if (g_attn_light_last == 1) return v & 1;
+    if (g_attn_light_last == 2) return v | 2;
     return v;
 }
 

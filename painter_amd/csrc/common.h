@@ -119,6 +119,8 @@ DEVI float wave_max(float v) {
 inline int g_relpos_splits = 0;
 // pa_debug_set(7, v): 0 = default (fused rel-pos table gradient in the generation-3 dQ kernel unless PA_ATTN3_FUSE_RELPOS=0), 1 = off, 2 = on
 inline int g_attn3_fuse = 0;
+// pa_debug_set(8, v): 0 = default (light attention workgroups dispatched last unless PA_ATTN_LIGHT_LAST=0), 1 = off, 2 = on
+inline int g_attn_light_last = 0;
 
 // exact (erf) GELU and its derivative -- nn.GELU default (Painter/models_painter.py:253)
 DEVI float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

@@ -36,6 +36,7 @@ __global__ __launch_bounds__(256) void sparse_rows_kernel(const int* __restrict_
     if (n < D) {
         for (int j = jl; j < K; j += 4) {
             const float m = val[(size_t)r * K + j];
+            if (m == 0.f) continue;            // padding entries (idx 0, val 0) must not touch row 0: 0 * inf would spread a NaN of an overflowed step
             const size_t o = (size_t)idx[(size_t)r * K + j] * D + n;
             acc = fmaf(m, x1 ? x0[o] + x1[o] : x0[o], acc);
         }

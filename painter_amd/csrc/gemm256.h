@@ -124,10 +124,19 @@ template <> struct Frag4<true> {
 // ~280 for the MFMA segment: 59 % matrix-pipe utilisation in the main loop).  Moving issues between the MFMAs balances the two.
 // The counted wait shrinks by ILV (the pieces of this phase that are not issued yet do not count); every hazard distance of the
 // header comment only grows (a unit is re-staged later, never earlier; it is still waited for >= 1 barrier before its first read).
-template <bool AMM, bool BMM, int ILV, class Epi>
+// SHORT: 224 x 256 output tiles on the same workgroup (round 4).  12544 = 49 x 256 rows leave every R = 12544 launch with a last round
+// of 256-row tiles that fills 6 % (fc1: 784 tiles on 256 CUs) to 77 % (proj / fc2: 196) of the chip; 12544 = 56 x 224 gives 896 / 224
+// tiles of 7/8 the work each.  The tile keeps the 256-row LDS image and schedule; the lower wave row simply owns three 32-row blocks
+// instead of four: its fourth block (tile rows 224..255, which belong to the next tile) is staged but never read, multiplied or
+// stored -- 14 instead of 16 MFMAs per k-step on every SIMD (each SIMD hosts one wave of either row).  Same ascending K order per
+// output element: bit-identical results.  Only for a K-major A operand (forward and data-gradient GEMMs).
+constexpr int BM_SHORT = 224;
+template <bool AMM, bool BMM, int ILV, class Epi, bool SHORT = false>
 __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag, uint32_t lda, const bf16* __restrict__ Bg,
                                                       uint32_t ldb, Epi epi, int M, int N, int ktiles, int ktiles_per_split,
                                                       int tiles_n, int stagger, int order) {
+    static_assert(!(SHORT && AMM), "the 224-row tile is built for a K-major A operand");
+    constexpr int BMR = SHORT ? BM_SHORT : BM;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     // de-phasing of the first round (diagnostic knob, pa_debug_set(0, cycles)): the 256 workgroups that start together are delayed by
@@ -152,7 +161,7 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
     int tm, tn;
     if (order == 0) {
         constexpr int TR = 4, TC = 8;
-        const int tiles_m = (M + BM - 1) / BM;
+        const int tiles_m = (M + BMR - 1) / BMR;
         const int per_group = TR * tiles_n;
         const int gm = tile / per_group, rem = tile - gm * per_group;
         const int rg = min(TR, tiles_m - gm * TR);                   // row panels in this (possibly last, shorter) group
@@ -170,7 +179,8 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
         tm = tile / tiles_n;
         tn = tile - tm * tiles_n;
     }
-    const int i0 = tm * BM, j0 = tn * BN;
+    const int i0 = tm * BMR, j0 = tn * BN;
+    const bool blk3 = !(SHORT && wr == 1);          // does this wave own the fourth 32-row block of its 128 rows?  (wave-uniform)
     const int split = blockIdx.y;
     const int kt0 = split * ktiles_per_split;
     const int nt = min(ktiles - kt0, ktiles_per_split);
@@ -242,7 +252,8 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
     // the MFMA takes the B fragment first so that a lane ends up with ONE output row and 4-column runs (wide stores)
 #define G256_MMA(KS)                                                                                                     \
     acc[mrow * 2 + 0][ncol] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr.template k<KS>(), fa0.template k<KS>(), acc[mrow * 2 + 0][ncol], 0, 0, 0); \
-    acc[mrow * 2 + 1][ncol] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr.template k<KS>(), fa1.template k<KS>(), acc[mrow * 2 + 1][ncol], 0, 0, 0);
+    if (!SHORT || mrow == 0 || blk3)                                                                                     \
+        acc[mrow * 2 + 1][ncol] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr.template k<KS>(), fa1.template k<KS>(), acc[mrow * 2 + 1][ncol], 0, 0, 0);
     // d0 / d1: this phase's DMA pieces; issued between the MFMAs (order pinned) as far as ILV says, otherwise by the caller
     auto mma_quad = [&](int mrow, int ncol, const Frag4<BMM>& bfr, auto&& d0, auto&& d1) {
         __builtin_amdgcn_s_setprio(1);
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
         }
         // ---- phase 2: a1
         fa0.template read<unit_off(false, 1, S)>(ra, 0);
-        fa1.template read<unit_off(false, 1, S) + (AMM ? 0 : 4096)>(ra, 1);
+        if (!SHORT || blk3) fa1.template read<unit_off(false, 1, S) + (AMM ? 0 : 4096)>(ra, 1);
         {
             auto d0 = [&] { piece_a(0, S, t2, 0); };
             auto d1 = [&] { piece_a(0, S, t2, 1); };
@@ -361,11 +372,13 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     const int mb = half * 2 + m2;
+                    if (SHORT && mb == 3 && !blk3) continue;
                     rows[m2][st] = epi.row(i0 + wr * 128 + (mb >> 1) * 64 + (mb & 1) * 32 + st * 8 + rrow, jcol);
                 }
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2) {
                 const int mb = half * 2 + m2;
+                if (SHORT && mb == 3 && !blk3) continue;
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -391,34 +404,51 @@ static inline int per_split(int ktiles, int nsplit) {
     int per = (ktiles + nsplit - 1) / nsplit;
     return per + (per & 1);
 }
-template <bool AMM, bool BMM, int ILV, class Epi>
+template <bool AMM, bool BMM, int ILV, bool SHORT, class Epi>
 static int launch_ilv(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit, hipStream_t st);
 #ifndef G256_ILV_DEFAULT
 #define G256_ILV_DEFAULT 2     // round 3 (tools/gemm_ilv_ab.py, MI355X): 2 is 4-15 % faster than 0 on the forward GEMMs, 4-6 % on the data gradients,
 #endif                         // 2 % on the weight gradients, bit-identical results; 1 = 0.  In the training step the gain shrinks to ~1 % (DVFS)
+// Which row-tile height for an un-split launch with a K-major A operand: rounds of 256 workgroups x the tile's relative cost.
+// g_dbg[4] (pa_debug_set(4, v)): 0 = this rule, 1 = always 256 rows, 2 = 224 rows wherever the kernel can.  PA_G256_SHORT_COST: the
+// 224-row tile's cost relative to the 256-row tile in percent (default 92: 14 of 16 MFMAs, the full load segment and barriers).
+static inline bool use_short(int M, int N, int nsplit, bool amm) {
+    if (amm || nsplit != 1 || M < BM) return false;
+    if (g_dbg[4] == 1) return false;
+    if (g_dbg[4] == 2) return true;
+    static const int cost = [] { const char* v = getenv("PA_G256_SHORT_COST"); return v ? atoi(v) : 92; }();
+    const int tiles_n = (N + BN - 1) / BN;
+    const long t256 = (long)((M + BM - 1) / BM) * tiles_n, t224 = (long)((M + BM_SHORT - 1) / BM_SHORT) * tiles_n;
+    const long r256 = (t256 + 255) / 256 * 100, r224 = (t224 + 255) / 256 * cost;
+    return r224 < r256;
+}
 template <bool AMM, bool BMM, class Epi>
 static int launch(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit,
                   hipStream_t st) {
+    if constexpr (!AMM) {
+        if (use_short(M, N, nsplit, AMM)) return launch_ilv<AMM, BMM, G256_ILV_DEFAULT, true>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
+    }
 #ifdef G256_ILV_AB       // experiment build: all three schedules in one library, pa_debug_set(5, 1 + ILV) picks one at run time
     static const int env_ilv = [] { const char* v = getenv("PA_G256_ILV"); return v ? atoi(v) : G256_ILV_DEFAULT; }();
     const int ilv = g_dbg[5] > 0 ? g_dbg[5] - 1 : env_ilv;
-    if (ilv == 2) return launch_ilv<AMM, BMM, 2>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
-    if (ilv == 1) return launch_ilv<AMM, BMM, 1>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
-    return launch_ilv<AMM, BMM, 0>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
+    if (ilv == 2) return launch_ilv<AMM, BMM, 2, false>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
+    if (ilv == 1) return launch_ilv<AMM, BMM, 1, false>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
+    return launch_ilv<AMM, BMM, 0, false>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
 #else
-    return launch_ilv<AMM, BMM, G256_ILV_DEFAULT>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
+    return launch_ilv<AMM, BMM, G256_ILV_DEFAULT, false>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
 #endif
 }
-template <bool AMM, bool BMM, int ILV, class Epi>
+template <bool AMM, bool BMM, int ILV, bool SHORT, class Epi>
 static int launch_ilv(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit, hipStream_t st) {
-    auto kern = gemm256_kernel<AMM, BMM, ILV, Epi>;
+    auto kern = gemm256_kernel<AMM, BMM, ILV, Epi, SHORT>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    constexpr int BMR = SHORT ? BM_SHORT : BM;
+    const int tiles_m = (M + BMR - 1) / BMR, tiles_n = (N + BN - 1) / BN;
     const int ktiles = K / BK;
     const int per = per_split(ktiles, nsplit);
     const int splits = (ktiles + per - 1) / per;      // every split gets an even number (>= 2) of tiles

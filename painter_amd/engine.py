@@ -30,6 +30,9 @@ _DBG_TRACE = os.environ.get("PAINTER_AMD_DEBUG_TRACE", "0") == "1"     # checksu
 
 _SIDE_STREAM = os.environ.get("PAINTER_AMD_SIDE_STREAM", "1") != "0"
 _configured = False
+# sizing of the parameter-gradient kernels when they run on the side stream, beside the data-gradient chain (0 = stand-alone sizing)
+WGRAD_SIDE_TARGET = 128
+RELPOS_SIDE_SPLITS = 8
 
 
 def _configure_library():
@@ -39,14 +42,14 @@ def _configure_library():
     if _configured:
         return
     from ._lib import lib
-    lib.pa_debug_set(6, 8 if _SIDE_STREAM else 0)       # K splits of the rel-pos table-gradient GEMM beside the main chain: round 2: 16 -> 54.54, 4 -> 54.35, 2 -> 55.0 ms/step; round 3 (tools/knob_sweep.py): 2 -> 56.18, 4 -> 55.10, 8 -> 54.89
-    lib.pa_debug_set(3, 128 if _SIDE_STREAM else 0)     # wgrad GEMM workgroup target (gemm.hip: wgrad_fast_splits); round-2 sweep: 64 -> 59.7, 96 -> 57.7, 128 -> 57.7, 192 -> 58.9, 256 -> 59.2 ms/step
+    lib.pa_debug_set(6, RELPOS_SIDE_SPLITS if _SIDE_STREAM else 0)       # K splits of the rel-pos table-gradient GEMM beside the main chain: round 2: 16 -> 54.54, 4 -> 54.35, 2 -> 55.0 ms/step; round 3 (tools/knob_sweep.py): 2 -> 56.18, 4 -> 55.10, 8 -> 54.89
+    lib.pa_debug_set(3, WGRAD_SIDE_TARGET if _SIDE_STREAM else 0)     # wgrad GEMM workgroup target (gemm.hip: wgrad_fast_splits); round-2 sweep: 64 -> 59.7, 96 -> 57.7, 128 -> 57.7, 192 -> 58.9, 256 -> 59.2 ms/step
     _configured = True
 
 
 class HotPathConfig:
     def __init__(self, img_size, patch_size, embed_dim, depth, num_heads, mlp_ratio, decoder_embed_dim,
-                 pretrain_img_size, pretrain_use_cls_token, use_rel_pos, ln_eps, loss_func, seggpt, drop_path_rate):
+                 pretrain_img_size, pretrain_use_cls_token, use_rel_pos, ln_eps, loss_func, seggpt, drop_path_rate, taps=None):
         self.H, self.W = img_size
         self.P = patch_size
         self.D = embed_dim
@@ -63,8 +66,8 @@ class HotPathConfig:
         self.loss_func = loss_func
         self.seggpt = seggpt
         self.merge_idx = 2                                   # models_painter.py:408
-        # models_painter.py:416 hard-codes [5, 11, 17, 23] (= depth/4*k - 1 at depth 24); generalised for other depths
-        self.taps = [5, 11, 17, 23] if depth == 24 else [depth // 4 * k - 1 for k in range(1, 5)]
+        # models_painter.py:416 hard-codes [5, 11, 17, 23]; another schedule has to be asked for explicitly (Painter(feature_taps=...))
+        self.taps = [5, 11, 17, 23] if taps is None else [int(t) for t in taps]
         self.dpr = hostmath.drop_path_rates(drop_path_rate, depth)
         self.scale = (embed_dim // num_heads) ** -0.5
         self.check()
@@ -81,8 +84,9 @@ class HotPathConfig:
         if self.D % 8 or self.hidden % 8: err.append("embed/hidden dims must be multiples of 8")
         if not self.use_rel_pos: err.append("use_rel_pos=False is not built (the reference factories always enable it)")
         if self.H != 2 * self.W: err.append("img_size must be (2W, W) (patchify asserts H == 2W, models_painter.py:361)")
-        if self.merge_idx >= self.depth or len(set(self.taps)) != 4 or self.taps[-1] != self.depth - 1:
-            err.append("depth %d incompatible with merge/tap schedule" % self.depth)
+        if self.merge_idx >= self.depth or len(set(self.taps)) != 4 or sorted(self.taps) != self.taps or self.taps[-1] != self.depth - 1:
+            err.append("depth %d is incompatible with the feature taps %s (four increasing blocks, the last one the last block; the reference's "
+                       "hard-coded [5, 11, 17, 23] only fits depth 24 -- pass feature_taps=..., e.g. depth/4*k - 1)" % (self.depth, self.taps))
         if self.merge_idx in self.taps or min(self.taps) < self.merge_idx:
             # the backward handles a block that is a feature tap OR the stream merge, and taps are taken on the merged stream
             err.append("depth %d puts a feature tap at or before the stream merge (block %d)" % (self.depth, self.merge_idx))
@@ -161,7 +165,10 @@ class HotPath:
 
     def relpos(self, pre, P, transposed):
         """Rcat / Rcat^T operands of block `pre`, packed once per parameter version (they used to be re-packed in every forward and
-        every backward of every block: 48 tiny launches per step)."""
+        every backward of every block: 48 tiny launches per step).  What this saves depends on the loop: the versions only stand still
+        between optimizer steps -- forward + backward timing (bench.py), evaluation, gradient-accumulation micro-steps; in plain training
+        every step re-packs (the fused AdamW refreshes the bf16 WEIGHT copies, not these).  Like every cache here it is keyed on the
+        tensor version: a write that does not bump it (p.data.copy_, an in-place collective) needs HotPath.invalidate()."""
         c = self.cfg
         rh, rw = P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"]
         key = (pre, transposed, rh.data_ptr(), rw.data_ptr())
@@ -172,6 +179,13 @@ class HotPath:
             self._rcache[key] = (ver, buf)
             return buf
         return ent[1]
+
+    def invalidate(self):
+        """Drop every cached operand copy (bf16 weights, packed patch weight, Rcat / Rcat^T): call after writing parameters in a way
+        that leaves their version counters alone."""
+        self._wcache.clear()
+        self._pcache.clear()
+        self._rcache.clear()
 
     def shadow_buffers(self):
         """{parameter data_ptr: cached bf16 copy} -- lets painter_amd.optim.AdamW refresh the copies inside its update pass."""

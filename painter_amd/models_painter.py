@@ -146,7 +146,11 @@ class Painter(nn.Module):
                  qkv_bias=True, drop_path_rate=0., norm_layer=nn.LayerNorm, act_layer=nn.GELU, use_abs_pos=True,
                  use_rel_pos=False, rel_pos_zero_init=True, window_size=0, window_block_indexes=(), residual_block_indexes=(),
                  use_act_checkpoint=False, pretrain_img_size=224, pretrain_use_cls_token=True, out_feature="last_feat",
-                 decoder_embed_dim=128, loss_func="smoothl1", compute_dtype=None):
+                 decoder_embed_dim=128, loss_func="smoothl1", compute_dtype=None, feature_taps=None):
+        """compute_dtype, feature_taps: extensions (keyword-only in practice; every reference argument keeps its position and default).
+        feature_taps: the four blocks whose output feeds the decoder.  None = the reference's hard-coded [5, 11, 17, 23]
+        (models_painter.py:416), which is only a usable schedule at depth 24; any other depth has to name its taps (the ViT-H/14 factory
+        below passes depth/4*k - 1) -- a checkpoint trained with the reference class at such a depth would compute a different function."""
         super().__init__()
         if in_chans != 3 or not use_abs_pos or not qkv_bias:
             raise NotImplementedError("HIP path is built for in_chans=3, use_abs_pos=True, qkv_bias=True (the reference factories)")
@@ -205,7 +209,7 @@ class Painter(nn.Module):
                                   num_heads=num_heads, mlp_ratio=mlp_ratio, decoder_embed_dim=decoder_embed_dim,
                                   pretrain_img_size=pretrain_img_size, pretrain_use_cls_token=pretrain_use_cls_token,
                                   use_rel_pos=use_rel_pos, ln_eps=ln_eps, loss_func=loss_func, seggpt=self._SEGGPT,
-                                  drop_path_rate=drop_path_rate)
+                                  drop_path_rate=drop_path_rate, taps=feature_taps)
         self._hot = HotPath(self._cfg, self.compute_dtype)
         self.grad_sync = None          # optional painter_amd.parallel.GradSync (bucketed RCCL all-reduce inside backward)
 
@@ -331,7 +335,7 @@ def painter_vit_huge_patch14_input896x448(**kwargs):
         drop_path_rate=0.1, window_size=14, qkv_bias=True,
         mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
         window_block_indexes=(), residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat",
-        decoder_embed_dim=64, loss_func="smoothl1", **kwargs)
+        decoder_embed_dim=64, loss_func="smoothl1", feature_taps=(7, 15, 23, 31), **kwargs)
 
 
 # names used by BASELINE.json

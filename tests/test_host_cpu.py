@@ -166,3 +166,19 @@ def test_sparse_rows_is_a_lossless_form_of_the_position_operator():
                 np.add.at(back[r], idx[r], val[r])
             assert np.array_equal(back, mat)
         assert hostmath.sparse_rows(m)[2] <= 16                      # 4 x 4 bicubic taps per output token
+
+
+def test_feature_taps_default_to_the_references_list_and_other_depths_must_name_theirs():
+    """models_painter.py:416 hard-codes the taps [5, 11, 17, 23]; the constructor keeps that default (depth 24: every reference factory) and
+    refuses a depth it does not fit unless `feature_taps` names a schedule -- the ViT-H/14 entry point passes depth/4*k - 1."""
+    from painter_amd import models_painter
+    kw = dict(img_size=(128, 64), patch_size=16, embed_dim=64, num_heads=1, decoder_embed_dim=64, use_rel_pos=True)
+    assert models_painter.Painter(depth=24, **kw)._cfg.taps == [5, 11, 17, 23]
+    with pytest.raises(NotImplementedError, match="feature_taps"):
+        models_painter.Painter(depth=16, **kw)
+    with pytest.raises(NotImplementedError, match="feature_taps"):
+        models_painter.Painter(depth=32, **kw)                      # the reference list would leave blocks 24-31 without gradient
+    assert models_painter.Painter(depth=16, feature_taps=(3, 7, 11, 15), **kw)._cfg.taps == [3, 7, 11, 15]
+    import inspect
+    src = inspect.getsource(models_painter.painter_vit_huge_patch14_input896x448)
+    assert "feature_taps=(7, 15, 23, 31)" in src

@@ -108,6 +108,36 @@ def test_gemm256_fast_path(M, N, K):
     assert torch.equal(dw, ops.linear_wgrad(dy, x2))
 
 
+@pytest.mark.parametrize("M,N,K", [(12544, 1024, 1024), (1568, 3072, 1024), (500, 264, 256), (448, 4096, 384), (3136, 1024, 4096)])
+def test_gemm256_224_row_tile_bit_identical_to_256_row_tile(M, N, K):
+    """The 224 x 256 tile of gemm256 (round 4: 12544 = 56 x 224 rows fill the last round of workgroups, the lower wave row owns three
+    32-row blocks) against the 256 x 256 tile on the same operands -- every epilogue of the forward and data-gradient GEMMs, whole and
+    ragged M (clamped rows, masked stores, a last 224-row tile that is mostly padding): the K order per output element is the same,
+    so the results must be bit-identical.  pa_debug_set(4, 1 / 2) pins the tile height."""
+    from painter_amd._lib import lib
+    T = torch.bfloat16
+    x, w, b = gen((M, K), 1, 1.0, T), gen((N, K), 2, 0.05, T), gen((N,), 3)
+    resid = gen((M, N), 4)
+    rowscale = gen(((M + 7) // 8,), 5).abs() + 0.5
+    dy, w2, pre2 = gen((M, N), 6, 1.0, T), gen((N, K), 7, 0.05, T), gen((M, K), 9, 1.0, T)
+
+    def run():
+        act, pre = ops.linear_gelu(x, w, b)
+        return (ops.linear_fwd(x, w, b, EPI_BIAS), ops.linear_fwd(x, w, b, EPI_BIAS_F32), act, pre,
+                ops.linear_fwd(x, w, b, EPI_BIAS_RESID, resid=resid, rowscale=rowscale, rows_per_sample=8),
+                ops.linear_dgrad(dy, w2), ops.linear_dgrad(dy, w2, pre=pre2))
+    try:
+        assert lib.pa_debug_set(4, 1) == 0
+        ref = run()
+        assert lib.pa_debug_set(4, 2) == 0
+        got = run()
+    finally:
+        lib.pa_debug_set(4, 0)
+    for a, r in zip(got, ref):
+        assert torch.equal(a, r)
+    assert relerr(ref[1], x.float() @ w.float().t() + b) < 2e-5 * math.sqrt(K)
+
+
 def _rel64(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

@@ -24,7 +24,8 @@ def build(cfg, seed, dtype, train=False):
     m = cls(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
             drop_path_rate=0.1, window_size=14, qkv_bias=True, mlp_ratio=4, norm_layer=partial(nn.LayerNorm, eps=1e-6),
             window_block_indexes=([0, 1], [3, 4]), residual_block_indexes=[], use_rel_pos=True, out_feature="last_feat",
-            decoder_embed_dim=cfg.decoder_embed_dim, loss_func=cfg.loss_func, compute_dtype=dtype)
+            decoder_embed_dim=cfg.decoder_embed_dim, loss_func=cfg.loss_func, compute_dtype=dtype,
+            **({} if cfg.depth == 24 else {"feature_taps": cfg.taps}))       # depth 24: the reference's own call, its hard-coded taps
     assert tuple(m._cfg.taps) == tuple(cfg.taps) and m._cfg.merge_idx == cfg.merge_idx
     P = O.random_params(cfg, seed)
     missing = m.load_state_dict(P, strict=True)

@@ -116,3 +116,28 @@ def test_two_ranks_on_one_gpu_average_the_hip_models_gradients(wrapper):
     assert res[0][0] and res[1][0], "broadcast_parameters left the replicas different"
     assert res[0][1] == res[1][1], "ranks ended with different gradients"
     assert res[0][2] is not None and res[0][2] < 2e-6, res[0][2]          # = mean over ranks of the local gradients (fp32 sum of two terms)
+
+
+def test_bench_multi_rank_branch_runs_with_two_gloo_ranks_on_one_gpu():
+    """`python bench.py --gpus 2 --backend gloo`: the N > 1 branch of the benchmark itself -- self-relaunch under torch.distributed.run,
+    `init_distributed`, differently seeded replicas + `broadcast_parameters`, `GradSync` fed from inside the backward, the barrier-
+    bracketed region, the MAX-over-ranks time, rank 0's single JSON line -- with two ranks sharing this box's one MI355X (gloo, because
+    RCCL refuses two ranks per device).  The line must say it is the debug arrangement; value = 2 ranks x batch x steps / time."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
+                        "--batch", "1", "--min-seconds", "0", "--profile-steps", "0", "--no-cpu-baseline", "--no-optimizer"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["config"]["global_batch"] == 2 and out["config"]["parallelism"] == "dp2"
+    assert out["config"]["backend"].startswith("gloo") and out["config"]["rccl_ranks"] == 0
+    assert out["value"] > 0 and abs(out["value"] - 2 * 1 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-2 * out["value"]
+    assert out["loss"] == out["loss"] and out["build"]["lib_sha16"]

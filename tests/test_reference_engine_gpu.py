@@ -4,10 +4,11 @@
 `util.lr_sched.adjust_learning_rate`, a plain `torch.optim.AdamW`) and `SegGPT_inference/seggpt_engine.py:run_one_image` are imported
 from a reference checkout through oracle/ref_import.py (stand-ins only for the absent third-party modules) and handed OUR modules.
 
-Needs BOTH an MI355X and the reference tree (PAINTER_REFERENCE_ROOT, default /root/reference): the GPU boxes of this project have no
-reference tree and the build container has no GPU, so here the run itself is skipped -- the first machine that has both executes it.
-What CAN be checked without a GPU is checked in tests/test_reference_import_cpu.py: the unmodified drivers import through the stubs
-and every attribute of the model they touch exists on our classes."""
+Needs BOTH an MI355X and the reference's driver files.  The GPU boxes of this project have no /root/reference: since round 4 the few
+unmodified files the drivers consist of travel there as oracle/_ref/reference_subset.tar.gz (staged by oracle/stage_ref.py from
+__graft_entry__.build() in the build container, git-ignored, SHA-256 manifest beside it) and oracle/ref_import.py unpacks them on first
+use -- so these tests RUN on the GPU box.  tests/test_reference_import_cpu.py is the build-container half: the drivers import through
+the stubs, every attribute of the model they touch exists on our classes, the staged copies are byte-identical to the reference."""
 import types
 
 import pytest
@@ -17,7 +18,7 @@ from oracle import painter_oracle as O
 from oracle import ref_import
 
 pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(not ref_import.reference_available(), reason="no reference checkout (PAINTER_REFERENCE_ROOT)"),
+              pytest.mark.skipif(not ref_import.reference_available(), reason="no reference files: neither PAINTER_REFERENCE_ROOT, /root/reference nor the staged oracle/_ref/ archive"),
               pytest.mark.skipif(not torch.cuda.is_available(), reason="needs an MI355X")]
 
 

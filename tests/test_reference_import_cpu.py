@@ -68,3 +68,37 @@ def test_run_one_image_expectation_of_the_gpu_test_holds_for_the_reference_model
     y = O.unpatchify(yo, cfg.patch_size).permute(0, 2, 3, 1)
     ref = torch.clip((y[0, y.shape[1] // 2:] * torch.tensor(O.IMAGENET_STD) + torch.tensor(O.IMAGENET_MEAN)) * 255, 0, 255)
     assert out.shape == ref.shape and float((out - ref).abs().max()) < 1e-2
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/Painter"), reason="needs the mounted reference tree to compare against")
+def test_staged_reference_subset_is_byte_identical_to_the_reference_and_is_what_the_gpu_box_imports(tmp_path, monkeypatch):
+    """oracle/stage_ref.py (run by __graft_entry__.build()): the archive under the git-ignored oracle/_ref/ holds byte-for-byte copies of
+    exactly the listed reference files, unpacks into a directory the loader accepts as a reference root, and a process that cannot see
+    /root/reference (the GPU box) imports the drivers from there."""
+    import hashlib
+    import subprocess
+    import sys
+
+    from oracle import stage_ref
+    assert stage_ref.stage(verbose=False) == len(stage_ref.FILES)
+    root = stage_ref.unpack()
+    for rel in stage_ref.FILES:
+        a = open(os.path.join("/root/reference", rel), "rb").read()
+        b = open(os.path.join(root, rel), "rb").read()
+        assert hashlib.sha256(a).hexdigest() == hashlib.sha256(b).hexdigest(), rel
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # nothing of the reference is tracked by git: the staging area is ignored as a whole
+    out = subprocess.run(["git", "-C", repo, "check-ignore", "oracle/_ref/reference_subset.tar.gz"], capture_output=True, text=True)
+    assert out.returncode == 0
+    code = ("import os, sys; sys.path.insert(0, %r)\n"
+            "real = os.path.isfile\n"
+            "os.path.isfile = lambda p: False if str(p).startswith('/root/reference') else real(p)\n"
+            "from oracle import ref_import as r\n"
+            "assert r.reference_available() and not r.REFERENCE_ROOT.startswith('/root/reference'), r.REFERENCE_ROOT\n"
+            "e = r.load_reference_engine_train(); s = r.load_reference_seggpt_engine(); m = r.load_reference_painter()\n"
+            "assert callable(e.train_one_epoch) and callable(s.run_one_image) and hasattr(m, 'Painter')\n"
+            "print('ok', r.REFERENCE_ROOT)\n") % repo
+    env = dict(os.environ)
+    env.pop("PAINTER_REFERENCE_ROOT", None)
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert res.returncode == 0 and res.stdout.startswith("ok"), res.stderr[-2000:]

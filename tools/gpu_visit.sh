@@ -34,6 +34,9 @@ for s in "$@"; do
                   n=$(echo $c | cut -d' ' -f1); timeout 600 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OLDPWD/gpurun_out/pmcattn_$n -o pmc -- env PYTHONPATH=$OLDPWD python $OLDPWD/tools/attn_bench.py > $OLDPWD/gpurun_out/pmcattn_$n.log 2>&1; done); echo "pmcattn done" ;;
     finaltests) timeout 300 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -s -x -k "gemm256 or vit_large_b8 or abs_pos" > gpurun_out/finaltests.log 2>&1; echo "finaltests rc=$?"; tail -4 gpurun_out/finaltests.log ;;
     lnpatch)   timeout 200 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_parallel_gpu.py tests/test_boundary_gpu.py -m gpu -q -s -x -k "layernorm or small or h14_fp32 or b8_train_bf16 or (two_ranks and GradSync) or bare_module" > gpurun_out/lnpatch.log 2>&1; echo "lnpatch rc=$?"; tail -4 gpurun_out/lnpatch.log ;;
+    r4tests)   timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_reference_engine_gpu.py tests/test_parallel_gpu.py -m gpu -q -s -x -k "attn or gemm256 or layernorm or small or b8_train_bf16 or vit_large_b1 or reference or bench_multi or c_abi" > gpurun_out/r4tests.log 2>&1; echo "r4tests rc=$?"; tail -8 gpurun_out/r4tests.log ;;
+    r4ab)      timeout 600 python tools/r04_ab.py 3 6 > gpurun_out/r4ab.log 2>&1; echo "r4ab rc=$?"; tail -8 gpurun_out/r4ab.log ;;
+    attnbench) timeout 300 python tools/attn_bench.py > gpurun_out/attnbench.log 2>&1; echo "attnbench rc=$?"; tail -12 gpurun_out/attnbench.log ;;
     *)         echo "unknown section $s" ;;
   esac
 done

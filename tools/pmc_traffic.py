@@ -42,6 +42,14 @@ def main():
                     "hbm_read_bytes": int(2 * fk * 1024), "hbm_write_bytes": int(wk * 1024),
                     "hbm_bytes_per_launch": int(2 * fk * 1024 + wk * 1024),
                     "note": "read = 2 x FETCH_SIZE (gfx950 wide-read correction), write = WRITE_SIZE as reported"}
+    # which build the counters belong to: bench.py refuses the file when the library it loads has another hash
+    import hashlib
+    import os
+    sys.path.insert(0, ".")
+    from painter_amd._lib import LIB_PATH
+    res["_meta"] = {"lib_sha16": hashlib.sha256(open(LIB_PATH, "rb").read()).hexdigest()[:16],
+                    "git_head": os.environ.get("PAINTER_AMD_GIT_HEAD") or (json.load(open("painter_amd/lib/build_info.json")).get("git_head") if os.path.exists("painter_amd/lib/build_info.json") else None),
+                    "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1"}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 
