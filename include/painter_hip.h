@@ -45,7 +45,8 @@ int pa_abi_version(void);
  * of the weight-gradient GEMM (0 = 256, the whole chip; 64 when the weight gradients run on a side stream); 4 = row-tile height of the un-split bf16
  * GEMMs: 0 by rule (224 rows where that fills the last round of workgroups better), 1 always 256, 2 224 wherever possible; 6 = K splits of the
  * rel-pos table-gradient GEMM; 7 = rel-pos table gradient inside the generation-3 dQ kernel: 0 default (on), 1 off, 2 on (tests);
- * 8 = generation-3 attention: workgroups with idle waves dispatched last: 0 default (on), 1 off, 2 on. */
+ * 8 = generation-3 attention: workgroups with idle waves dispatched last: 0 default (on), 1 off, 2 on;
+ * 9 = generation-4 (64-row waves, csrc/attn4.hip) dQ kernel: 0 default (off: experiment), 1 off, 2 on (its parity test). */
 int pa_debug_set(int which, int value);
 
 /* ---- nn.Linear: y = x W^T + b.  models_painter.py:76 (qkv), :87 (proj), timm Mlp fc1/fc2 (:201,:230) ---- */
@@ -98,6 +99,8 @@ int pa_attn_set_generation(int generation);
 /* diagnostics: enable != 0 runs the generation-3 dQ kernel with s_memtime stamps (two workgroups, waves 0 / 1, 64 tiles, 8 slots);
  * host_out (may be NULL) receives the 2 x 2 x 64 x 8 stamps of the last traced launch */
 int pa_attn_trace(int enable, unsigned long long* host_out);
+/* diagnostics: the 64 x 8 s_memtime stamps of the generation-4 dQ kernel's stamped experiment variant (all zero in product builds) */
+int pa_attn4_trace(unsigned long long* host_out);
 int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse,
                 void* tables, int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t stream);
 

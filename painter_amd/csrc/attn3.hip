@@ -215,7 +215,9 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
                                                           const bf16* __restrict__ dout, size_t lddo, const float* __restrict__ lse,
                                                           const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv,
                                                           bf16* __restrict__ dG, float* __restrict__ part, int L, int H, int Hp, int NRP,
-                                                          float scale, int nblk, int xcd_map, int abl) {
+                                                          float scale, int nblk, int xcd_map, int abl, int tile0, int pslot0) {
+    // tile0: first 32-query tile of every head this launch covers (generation 4 takes the whole 8-tile groups below it, attn4.hip);
+    // pslot0: first partial slot of this launch in `part`
     // abl (diagnostics, PA_ATTN3_DQ_ABL; results are WRONG with any bit set): 1 no r-space loop after the key loop, 2 no dG stores,
     // 4 no dQ store, 16 no key loop, 32 no gather in the r-space loop, 64 no MFMA in the r-space loop
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -231,12 +233,12 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     };
     coarse(60);
     int blk, bh;
-    wg_coords(nblk, xcd_map, blk, bh, (L / 32) / NW);
+    wg_coords(nblk, xcd_map, blk, bh, (L / 32 - tile0) / NW);
     const int b = bh / H, h = bh % H, D = H * ATT_HD;
     const bf16* base = qkv + (size_t)b * L * ldq + h * ATT_HD;
     const bf16* kbase = base + D;
     const bf16* vbase = base + 2 * D;
-    const int qt = blk * NW + wave;
+    const int qt = tile0 + blk * NW + wave;
     const bool valid = qt * 32 < L;
     const int q = qt * 32 + ql;
     const int qh = q / WP, qw = q % WP;
@@ -518,11 +520,11 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
                 *reinterpret_cast<uint4*>(wimg + nimg * IMG + ql * 128 + (((2 * s + g) ^ rsw) << 4)) = __builtin_bit_cast(uint4, qf[s]);
         }
         __syncthreads();
-        float* pw = part + (size_t)blockIdx.x * NRP * ATT_HD;
+        float* pw = part + (size_t)(pslot0 + blockIdx.x) * NRP * ATT_HD;
         for (int rb = wave; rb < NRP / 32; rb += NW) {
             f32x16 acc[2] = {zero16(), zero16()};
             for (int w2 = 0; w2 < NW; ++w2) {
-                if ((blk * NW + w2) * 32 >= L) break;         // that wave had no queries
+                if ((tile0 + blk * NW + w2) * 32 >= L) break;         // that wave had no queries
                 const unsigned char* im = smem + w2 * (nimg + 1) * IMG;
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
@@ -550,20 +552,21 @@ constexpr int DKV_TW = 2 * IMG, DKV_TH = DKV_TW + 2048, DKV_ND = DKV_TH + 512, D
 template <int MINW>
 __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ dout,
                                                            size_t lddo, const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv,
-                                                           int L, int H, int Hp, float scale, int nblk, int xcd_map, int abl) {
+                                                           int L, int H, int Hp, float scale, int nblk, int xcd_map, int abl, int tile0) {
     // abl (diagnostics, PA_ATTN3_DKV_ABL; results WRONG when set): 16 no query loop
+    // tile0: first 32-key tile of every head this launch covers (generation 4 takes the whole 8-tile groups below it)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, ql = lane & 31;
     int blk, bh;
-    wg_coords(nblk, xcd_map, blk, bh, (L / 32) / NW);
+    wg_coords(nblk, xcd_map, blk, bh, (L / 32 - tile0) / NW);
     const int b = bh / H, h = bh % H, D = H * ATT_HD;
     const bf16* qbase = qkv + (size_t)b * L * ldq + h * ATT_HD;
     const bf16* dobase = dout + (size_t)b * L * lddo + h * ATT_HD;
-    const int kt = blk * NW + wave;
+    const int kt = tile0 + blk * NW + wave;
     const bool valid = kt * 32 < L;
     const int key = kt * 32 + ql;
     const int kh = key / WP, kw = key % WP;
-    const int khlo = (blk * NW * 32) / WP;            // first key row of the workgroup
+    const int khlo = ((tile0 + blk * NW) * 32) / WP;  // first key row of the workgroup
     const int kha = (kt * 32) / WP;                   // the wave's 32 keys lie in key rows kha and kha + 1
     const int ntile = L / 32;
     const int TB = ttile_bytes(Hp);
@@ -813,19 +816,23 @@ static int a3_fuse_on() {
     static const int v = [] { const char* e = getenv("PA_ATTN3_FUSE_RELPOS"); return e ? atoi(e) : 1; }();
     return g_attn3_fuse == 1 ? 0 : (g_attn3_fuse == 2 ? 1 : v);
 }
+// workgroups of the dQ launches = partial slots: generation 4 takes `ngrp` whole 8-tile groups per head, generation 3 the tiles behind them
+static int a3_rem_blocks(int L, int ngrp) { return (L / 32 - 8 * ngrp + a3::NW - 1) / a3::NW; }
+static int64_t a3_num_partials(int Bn, int L, int H, int Hp, int Wp) {
+    const int ngrp = attn4_groups(L, Hp, Wp);
+    return (int64_t)(ngrp + a3_rem_blocks(L, ngrp)) * Bn * H;
+}
 int64_t attn3_relpos_partials_bytes(int Bn, int L, int H, int Hp, int Wp) {
     if (!a3_fuse_on() || !attn3_ok(L, Hp, Wp)) return 0;
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
     if (NRP > 16 * a3::NSMAX) return 0;
-    const int nblk = (L / 32 + a3::NW - 1) / a3::NW;
-    return (int64_t)nblk * Bn * H * NRP * ATT_HD * sizeof(float);
+    return a3_num_partials(Bn, L, H, Hp, Wp) * NRP * ATT_HD * sizeof(float);
 }
 // part: what attn3_bwd's dQ kernel wrote; tmp: RED_ZC * NRP * 64 floats of scratch; drcat f32 [NRP][64], overwritten
 int attn3_relpos_reduce(const float* part, float* drcat, float* tmp, int Bn, int L, int H, int Hp, int Wp, hipStream_t st) {
     using namespace a3;
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
-    const int nblk = (L / 32 + NW - 1) / NW;
-    const int nz = nblk * Bn * H, n4 = NRP * ATT_HD / 4;
+    const int nz = (int)a3_num_partials(Bn, L, H, Hp, Wp), n4 = NRP * ATT_HD / 4;
     const int zc = nz < RED_ZC ? nz : RED_ZC;
     PA_LAUNCH(relpos_part_reduce_kernel, dim3((n4 + 63) / 64, zc), dim3(256), 0, st, reinterpret_cast<const float4*>(part),
               reinterpret_cast<float4*>(tmp), n4, nz);
@@ -837,7 +844,6 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
               void* tables, bf16* dqkv, bf16* dG, float* part, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st) {
     using namespace a3;
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
-    const int nblk = (L / 32 + NW - 1) / NW;
     if (part != nullptr && NRP > 16 * NSMAX) return (int)hipErrorInvalidValue;
     if (part == nullptr && dG == nullptr) return (int)hipErrorInvalidValue;
     unsigned char* tb = reinterpret_cast<unsigned char*>(tables);
@@ -847,10 +853,16 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
         PA_LAUNCH(prep_kernel, dim3((total + 255) / 256), dim3(256), 0, st, lse, delta, tb, L, Hp, 1.f / scale, total);
         if ((e = (int)hipGetLastError())) return e;
     }
+    // generation 4 (attn4.hip, 64-row waves) takes the whole 8-tile groups of every head when the rel-pos gradient is fused; the tiles
+    // behind them (the 49th of 49 at the ViT-L grid) and every other case run here
+    const int ngrp = part != nullptr ? attn4_groups(L, Hp, Wp) : 0;
+    const int tile0 = 8 * ngrp;
+    const int nblk = a3_rem_blocks(L, ngrp);
     // PA_ATTN3_DQ_WAVES / PA_ATTN3_DKV_WAVES: waves per SIMD the register allocation aims at (2 or 3)
     static const int dq_w = [] { const char* v = getenv("PA_ATTN3_DQ_WAVES"); return v ? atoi(v) : 2; }();
     static const int dkv_w = [] { const char* v = getenv("PA_ATTN3_DKV_WAVES"); return v ? atoi(v) : 2; }();
-    {
+    if (ngrp > 0 && (e = attn4_bwd_dq(qkv, ldq, rcatT, dout, lddo, lse, tables, dqkv, part, Bn, L, H, Hp, Wp, scale, a3_xcd_map_on(), st))) return e;
+    if (nblk > 0) {
         static const size_t pad = [] { const char* v = getenv("PA_ATTN3_LDS_PAD"); return v ? (size_t)atoi(v) : (size_t)0; }();   // diagnostics: fewer workgroups per CU
         size_t smem = 2 * (size_t)STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG + (size_t)ATT_HD * (NRP * 2 + 16) + pad;
         const bool fuse = part != nullptr;
@@ -864,10 +876,13 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
         if ((e = set_smem(reinterpret_cast<const void*>(kern), fuse ? donef : (g_attn_trace ? donet : (dq_w == 3 ? done3 : done2))))) return e;
         const char* ablv = getenv("PA_ATTN3_DQ_ABL");           // diagnostics, read per launch
         PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcatT, dout, (size_t)lddo, lse, tb, dqkv, dG, part, L, H,
-                  Hp, NRP, scale, nblk, a3_xcd_map_on(), ablv ? atoi(ablv) : 0);
+                  Hp, NRP, scale, nblk, a3_xcd_map_on(), ablv ? atoi(ablv) : 0, tile0, ngrp * Bn * H);
         if ((e = (int)hipGetLastError())) return e;
     }
-    {
+    const int ngrp_kv = attn4_dkv_on() ? ngrp : 0;
+    if (ngrp_kv > 0 && (e = attn4_bwd_dkv(qkv, ldq, dout, lddo, tables, dqkv, Bn, L, H, Hp, Wp, scale, a3_xcd_map_on(), st))) return e;
+    const int tile0_kv = 8 * ngrp_kv, nblk_kv = a3_rem_blocks(L, ngrp_kv);
+    if (nblk_kv > 0) {
         size_t smem = 2 * (size_t)DKV_STAGE;
         if (smem < (size_t)NW * 2 * IMG) smem = (size_t)NW * 2 * IMG;
         static const size_t pad = [] { const char* v = getenv("PA_ATTN3_LDS_PAD"); return v ? (size_t)atoi(v) : (size_t)0; }();
@@ -875,8 +890,9 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
         auto kern = dkv_w == 3 ? bwd_dkv_kernel<3> : bwd_dkv_kernel<2>;
         static bool done2 = false, done3 = false;
         if ((e = set_smem(reinterpret_cast<const void*>(kern), dkv_w == 3 ? done3 : done2))) return e;
-        PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, dout, (size_t)lddo, tb, dqkv, L, H, Hp, scale, nblk,
-                  a3_xcd_map_on(), [] { const char* v = getenv("PA_ATTN3_DKV_ABL"); return v ? atoi(v) : 0; }());
-        return (int)hipGetLastError();
+        PA_LAUNCH(kern, dim3(nblk_kv * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, dout, (size_t)lddo, tb, dqkv, L, H, Hp, scale, nblk_kv,
+                  a3_xcd_map_on(), [] { const char* v = getenv("PA_ATTN3_DKV_ABL"); return v ? atoi(v) : 0; }(), tile0_kv);
+        if ((e = (int)hipGetLastError())) return e;
     }
+    return 0;
 }

@@ -121,6 +121,8 @@ inline int g_relpos_splits = 0;
 inline int g_attn3_fuse = 0;
 // pa_debug_set(8, v): 0 = default (light attention workgroups dispatched last unless PA_ATTN_LIGHT_LAST=0), 1 = off, 2 = on
 inline int g_attn_light_last = 0;
+// pa_debug_set(9, v): 0 = default (generation-4 64-row attention backward OFF unless PA_ATTN4=1: experiment, attn4.hip), 1 = off, 2 = on
+inline int g_attn4 = 0;
 
 // exact (erf) GELU and its derivative -- nn.GELU default (Painter/models_painter.py:253)
 DEVI float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

@@ -455,6 +455,7 @@ def test_attn3_fused_relpos_gradient_vs_dG_gemm(B, H, Hp, Wp):
     out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
     res = {}
     try:
+        assert lib.pa_debug_set(9, 1) == 0                  # generation 3 for every tile: the two routes then share the key loop bit for bit
         for mode in (2, 1, 2):
             assert lib.pa_debug_set(7, mode) == 0
             nb = lib.pa_attn_bwd_relpos_partials_bytes(PA_BF16, B, L, H, Hp, Wp, 64)
@@ -467,6 +468,7 @@ def test_attn3_fused_relpos_gradient_vs_dG_gemm(B, H, Hp, Wp):
             res[mode] = (dqkv.clone(), drcat.clone())
     finally:
         lib.pa_debug_set(7, 0)
+        lib.pa_debug_set(9, 0)
     assert torch.equal(res[1][0], res[2][0])
     assert relerr(res[2][1], res[1][1]) < 1e-5, relerr(res[2][1], res[1][1])
     q64 = qkv.double().clone().requires_grad_(True)
@@ -479,6 +481,46 @@ def test_attn3_fused_relpos_gradient_vs_dG_gemm(B, H, Hp, Wp):
         print("rel-pos table gradient vs fp64, mode %d (1 = dG + GEMM, 2 = fused): %.3e %.3e" % ((mode,) + e))
         assert max(e) < 1.6e-2
     assert float(res[2][1][nh + nw:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,H,Hp,Wp", [(2, 2, 56, 28), (1, 3, 16, 28), (2, 1, 24, 28)])
+def test_attn4_64_row_backward_vs_generation_3_and_fp64(B, H, Hp, Wp):
+    """Generation 4 (csrc/attn4.hip: one wave per SIMD owning two 32-row blocks, whole 8-tile groups of a head; the tiles behind them stay
+    on generation 3 with a tile offset) against generation 3 alone on the same inputs and tables, and against the fp64 reference of
+    models_painter.py:76-86 + vitdet_utils.py:96-125.  Grids: 49 tiles (6 groups + 1 tile), 14 tiles (1 group + 6 tiles in two
+    generation-3 workgroups, the second one light), 21 tiles (2 groups + 5).  Same math and the same bf16 operands, another summation
+    order: close to generation 3 (far inside the bf16 gate), bit-stable run to run."""
+    from painter_amd._lib import lib
+    L, qkv, rcat, rcatT, dout = _attn3_inputs(B, H, Hp, Wp)
+    nh, nw = 2 * Hp - 1, 2 * Wp - 1
+    out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
+    res = {}
+    try:
+        for mode in (2, 1, 2):
+            assert lib.pa_debug_set(9, mode) == 0
+            dqkv, dg = ops.attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables)
+            drcat = ops.attn_bwd_relpos(dg, qkv, rcat.shape[0], B, L, H, Hp, Wp)
+            if mode in res:
+                assert torch.equal(res[mode][0], dqkv) and torch.equal(res[mode][1], drcat)
+            res[mode] = (dqkv.clone(), drcat.clone())
+    finally:
+        lib.pa_debug_set(9, 0)
+    D = H * 64
+    e34 = dict(dq=relerr(res[2][0][:, :D].float(), res[1][0][:, :D].float()), dk=relerr(res[2][0][:, D:2 * D].float(), res[1][0][:, D:2 * D].float()),
+               dv=relerr(res[2][0][:, 2 * D:].float(), res[1][0][:, 2 * D:].float()), drel=relerr(res[2][1], res[1][1]))
+    print("generation 4 vs generation 3:", {k: "%.2e" % v for k, v in e34.items()})
+    assert max(e34.values()) < 8e-3, e34
+    q64 = qkv.double().clone().requires_grad_(True)
+    rh64 = rcat[:nh].double().clone().requires_grad_(True)
+    rw64 = rcat[nh:nh + nw].double().clone().requires_grad_(True)
+    ref, _ = attn_reference(q64, rh64, rw64, B, L, H, Hp, Wp, 0.125)
+    ref.backward(dout.double())
+    for mode in (1, 2):
+        dqkv, drcat = res[mode]
+        errs = dict(dq=relerr(dqkv[:, :D].float(), q64.grad[:, :D]), dk=relerr(dqkv[:, D:2 * D].float(), q64.grad[:, D:2 * D]),
+                    dv=relerr(dqkv[:, 2 * D:].float(), q64.grad[:, 2 * D:]), drh=relerr(drcat[:nh], rh64.grad), drw=relerr(drcat[nh:nh + nw], rw64.grad))
+        print("generation %d vs fp64:" % (2 + mode), {k: "%.2e" % v for k, v in errs.items()})
+        assert max(errs.values()) < 1.6e-2, errs
 
 
 @pytest.mark.parametrize("gen_", [0])

@@ -37,6 +37,7 @@ for s in "$@"; do
     r4tests)   timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py tests/test_reference_engine_gpu.py tests/test_parallel_gpu.py -m gpu -q -s -x -k "attn or gemm256 or layernorm or small or b8_train_bf16 or vit_large_b1 or reference or bench_multi or c_abi" > gpurun_out/r4tests.log 2>&1; echo "r4tests rc=$?"; tail -8 gpurun_out/r4tests.log ;;
     r4ab)      timeout 600 python tools/r04_ab.py 3 6 > gpurun_out/r4ab.log 2>&1; echo "r4ab rc=$?"; tail -8 gpurun_out/r4ab.log ;;
     attnbench) timeout 300 python tools/attn_bench.py > gpurun_out/attnbench.log 2>&1; echo "attnbench rc=$?"; tail -12 gpurun_out/attnbench.log ;;
+    a4tests)   timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -s -x -k "attn" > gpurun_out/a4tests.log 2>&1; echo "a4tests rc=$?"; grep -a "generation\|passed\|failed\|Error\|error" gpurun_out/a4tests.log | tail -30 ;;
     *)         echo "unknown section $s" ;;
   esac
 done

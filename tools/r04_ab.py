@@ -44,8 +44,12 @@ def main():
     for _ in range(3):
         step()
     OFF, ON = {4: 1, 7: 1, 8: 1}, {4: 0, 7: 2, 8: 2}
-    settings = [("all off (round-3 arrangement)", OFF), ("224-row GEMM tile only", dict(OFF, **{4: 0})), ("224-row tile everywhere", dict(OFF, **{4: 2})),
-                ("fused rel-pos gradient only", dict(OFF, **{7: 2})), ("light workgroups last only", dict(OFF, **{8: 2})), ("all on", ON)]
+    def with_(base, which, val):
+        d = dict(base)
+        d[which] = val
+        return d
+    settings = [("all off (round-3 arrangement)", OFF), ("224-row GEMM tile by rule only", with_(OFF, 4, 0)), ("224-row tile everywhere", with_(OFF, 4, 2)),
+                ("fused rel-pos gradient only", with_(OFF, 7, 2)), ("light workgroups last only", with_(OFF, 8, 2)), ("all on", ON)]
     res = {k: [] for k, _ in settings}
     for _ in range(rounds):
         for name, knobs in settings:
