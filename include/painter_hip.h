@@ -37,7 +37,7 @@ enum {
 };
 
 /* Bumped whenever an entry point's argument list changes (2: `tables` in pa_attn_fwd / pa_attn_bwd; 3: `head_dim` in the attention and
- * rel-pos entry points; 4: `dxT_colsum` in pa_layernorm_bwd, `relpos_part` in pa_attn_bwd).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
+ * rel-pos entry points; 4: `dxT_colsum` in pa_layernorm_bwd, `relpos_part` in pa_attn_bwd, `dx_colsum` in pa_linear_dgrad).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
 #define PA_ABI_VERSION 4
 int pa_abi_version(void);
 /* diagnostics only (tools/): which = 0 start-up stagger of alternate workgroup rows of the 256x256 GEMM in shader cycles,
@@ -57,10 +57,14 @@ int pa_linear_fwd(int dtype, int epilogue, const void* x /*T [M,K]*/, int64_t ld
 /* decoder_embed + pixel shuffle 'nhwpqc->nchpwq' (models_painter.py:423-428); output is NHWC [B, Hp*P, Wp*P, C] T */
 int pa_linear_pixshuf(int dtype, const void* x, int64_t ldx, const void* w /*T [P*P*C, K]*/, const float* bias,
                       void* out_nhwc, int batch, int Hp, int Wp, int P, int C, int K, hipStream_t stream);
-/* autograd of the above: dX = dY.W (optionally * gelu'(pre)), dW = dY^T.X (fp32), db = colsum(dY) */
+/* autograd of the above: dX = dY.W (optionally * gelu'(pre)), dW = dY^T.X (fp32), db = colsum(dY).
+ * dx_colsum (optional, f32 [K], with workspace = pa_linear_dgrad_workspace_bytes(M, K)): the column sums of dX as stored -- dX is the dY
+ * of the layer in front (fc1 behind the GELU), so this is that layer's bias gradient, taken in the GEMM's epilogue instead of a second
+ * pass over dX. */
+int64_t pa_linear_dgrad_workspace_bytes(int M, int K);
 int pa_linear_dgrad(int dtype, const void* dy /*T [M,N]*/, int64_t lddy, const void* w /*T [N,K]*/,
-                    const void* pre_for_dgelu /*T [M,K] ld=lddx or NULL*/, void* dx /*T [M,K]*/, int64_t lddx, int M, int N,
-                    int K, hipStream_t stream);
+                    const void* pre_for_dgelu /*T [M,K] ld=lddx or NULL*/, void* dx /*T [M,K]*/, int64_t lddx, float* dx_colsum,
+                    void* workspace, int M, int N, int K, hipStream_t stream);
 int64_t pa_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K);
 int pa_linear_wgrad(int dtype, const void* dy /*T [M,N]*/, int64_t lddy, const void* x /*T [M,K]*/, int64_t ldx,
                     float* dw /*f32 [N,K]*/, void* workspace, int M, int N, int K, hipStream_t stream);
@@ -120,6 +124,11 @@ int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* rel_pos_w, 
                      hipStream_t stream);
 int pa_attn_bwd_delta(int dtype, const void* out, int64_t ldo, const void* dout, int64_t lddo, float* delta, int batch,
                       int L, int heads, int head_dim, hipStream_t stream);
+/* pa_attn_bwd_prep_ok() == 1 (28-token-wide bf16 kernels, `tables` given): pa_attn_bwd_prep computes Delta AND writes it with the
+ * log-sum-exp fields into the table tiles in one pass; pa_attn_bwd is then called with delta = NULL (no pa_attn_bwd_delta launch). */
+int pa_attn_bwd_prep_ok(int dtype, int L, int Hp, int Wp, int head_dim);
+int pa_attn_bwd_prep(int dtype, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, void* tables,
+                     int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t stream);
 int64_t pa_attn_bwd_aux_bytes(int batch, int L, int heads, int Hp, int Wp);
 int64_t pa_attn_bwd_relpos_partials_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp, int head_dim);
 int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, const void* rcatT, const void* dout,

@@ -11,6 +11,10 @@ int attn3_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t
 // partial per workgroup there instead of dG; attn3_relpos_reduce() sums the partials into drcat [NRP][64]
 int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const float* delta,
               void* tables, bf16* dqkv, bf16* dG, float* part, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st);
+// Delta = rowsum(dO o O) computed and written (with -lse / scale hi + lo) straight into the table tiles: replaces pa_attn_bwd_delta + the prep
+// kernel of attn3_bwd, which then takes delta = NULL
+int attn3_bwd_prep(const bf16* out, int64_t ldo, const bf16* dout, int64_t lddo, const float* lse, void* tables, int Bn, int L, int H, int Hp,
+                   float scale, hipStream_t st);
 int64_t attn3_relpos_partials_bytes(int Bn, int L, int H, int Hp, int Wp);       // 0: not fused for this grid (or PA_ATTN3_FUSE_RELPOS=0)
 int attn3_relpos_reduce(const float* part, float* drcat, float* tmp, int Bn, int L, int H, int Hp, int Wp, hipStream_t st);
 // generation 4 (attn4.hip): 64-row waves for the backward; takes the whole 8-tile groups of every head, the rest stays on generation 3

@@ -735,7 +735,49 @@ __global__ void prep_kernel(const float* __restrict__ lse, const float* __restri
     *reinterpret_cast<float*>(tt + 2048 + (Hp + 2) * 64 + qi * 4) = -delta[idx];
 }
 
+// Delta = rowsum(dO o O) and the prep above in ONE pass (the backward of a block used to launch attn_delta_kernel, then prep_kernel):
+// one wave per token row, 4 lanes per head (16 elements each), the quad's first lane writes the head's three table fields
+__global__ __launch_bounds__(256) void prep_delta_kernel(const bf16* __restrict__ o, size_t ldo, const bf16* __restrict__ d_o, size_t lddo,
+                                                         const float* __restrict__ lse, unsigned char* __restrict__ tables, int R, int L, int H,
+                                                         int Hp, float inv_scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= R) return;
+    const int b = row / L, l = row - b * L, qt = l >> 5, qi = l & 31;
+    const int D = H * ATT_HD, TB = ttile_bytes(Hp);
+    for (int c = lane * 16; c < D; c += 1024) {
+        const uint4 o0 = *reinterpret_cast<const uint4*>(o + (size_t)row * ldo + c), o1 = *reinterpret_cast<const uint4*>(o + (size_t)row * ldo + c + 8);
+        const uint4 d0 = *reinterpret_cast<const uint4*>(d_o + (size_t)row * lddo + c), d1 = *reinterpret_cast<const uint4*>(d_o + (size_t)row * lddo + c + 8);
+        float s = 0.f;          // the element order of attn_delta_kernel (the same bits as the two-kernel route)
+        const uint32_t ow[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w}, dw[8] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s += bf16_lo(ow[e]) * bf16_lo(dw[e]);
+            s += bf16_hi(ow[e]) * bf16_hi(dw[e]);
+        }
+        s = quad_sum(s);
+        if ((lane & 3) == 0) {
+            const int bh = b * H + c / ATT_HD;
+            unsigned char* tt = tables + ((size_t)bh * (L / 32) + qt) * TB;
+            const float x = -lse[(size_t)bh * L + l] * inv_scale;
+            const bf16 hi = (bf16)x;
+            const bf16 lo = (bf16)(x - (float)hi);
+            *reinterpret_cast<bf16*>(tt + 2048 + Hp * 64 + qi * 2) = hi;
+            *reinterpret_cast<bf16*>(tt + 2048 + (Hp + 1) * 64 + qi * 2) = lo;
+            *reinterpret_cast<float*>(tt + 2048 + (Hp + 2) * 64 + qi * 4) = -s;
+        }
+    }
+}
+
 }   // namespace a3
+
+int attn3_bwd_prep(const bf16* out, int64_t ldo, const bf16* dout, int64_t lddo, const float* lse, void* tables, int Bn, int L, int H, int Hp,
+                   float scale, hipStream_t st) {
+    const int R = Bn * L;
+    PA_LAUNCH(a3::prep_delta_kernel, dim3((R + 3) / 4), dim3(256), 0, st, out, (size_t)ldo, dout, (size_t)lddo, lse,
+              reinterpret_cast<unsigned char*>(tables), R, L, H, Hp, 1.f / scale);
+    return (int)hipGetLastError();
+}
 
 // PA_ATTN3=0 / pa_attn_set_generation(2): keep the generation-2 kernels for every grid (A/B runs, cross-generation tests).  The paired
 // 8-wave build and the software-pipelined dQ of round 2 both measured slower and live in tools/experiments/ (DESIGN.md section 4.5).
@@ -848,7 +890,7 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
     if (part == nullptr && dG == nullptr) return (int)hipErrorInvalidValue;
     unsigned char* tb = reinterpret_cast<unsigned char*>(tables);
     int e;
-    {
+    if (delta != nullptr) {         // NULL: pa_attn_bwd_prep already filled the lse / -Delta fields of the tables
         const int total = Bn * H * L;
         PA_LAUNCH(prep_kernel, dim3((total + 255) / 256), dim3(256), 0, st, lse, delta, tb, L, Hp, 1.f / scale, total);
         if ((e = (int)hipGetLastError())) return e;

@@ -515,6 +515,16 @@ static int attn_bwd_t(const T* qkv, int64_t ldq, const T* rcat, const T* rcatT, 
 }
 
 // dqkv: T [batch*L, 3*heads*hd] (same layout as qkv); dG: T [batch*L, heads*NRP]; aux: pa_attn_bwd_aux_bytes scratch
+// 1 when the backward for this case reads Delta from the table tiles (28-token-wide bf16 kernels): pa_attn_bwd_prep replaces
+// pa_attn_bwd_delta and pa_attn_bwd is called with delta = NULL
+extern "C" int pa_attn_bwd_prep_ok(int dtype, int L, int Hp, int Wp, int head_dim) {
+    return (dtype == PA_BF16 && head_dim == ATT_HD && L == Hp * Wp && attn3_ok(L, Hp, Wp)) ? 1 : 0;
+}
+extern "C" int pa_attn_bwd_prep(int dtype, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, void* tables,
+                                int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t st) {
+    if (!pa_attn_bwd_prep_ok(dtype, L, Hp, Wp, head_dim) || tables == nullptr || ldo % 8 || lddo % 8) return (int)hipErrorInvalidValue;
+    return attn3_bwd_prep((const bf16*)out, ldo, (const bf16*)dout, lddo, lse, tables, batch, L, heads, Hp, scale, st);
+}
 extern "C" int64_t pa_attn_bwd_relpos_partials_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp, int head_dim) {
     if (dtype != PA_BF16 || head_dim != ATT_HD || L != Hp * Wp) return 0;
     return attn3_relpos_partials_bytes(batch, L, heads, Hp, Wp);
@@ -528,7 +538,7 @@ extern "C" int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* 
         return attn3_bwd((const bf16*)qkv, ldq, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, tables, (bf16*)dqkv, (bf16*)dG,
                          (float*)relpos_part, batch, L, heads, Hp, Wp, scale, st);
     }
-    if (relpos_part != nullptr || dG == nullptr) return (int)hipErrorInvalidValue;      // only the generation-3 kernels fuse the rel-pos gradient
+    if (relpos_part != nullptr || dG == nullptr || delta == nullptr) return (int)hipErrorInvalidValue;      // only the generation-3 kernels fuse the rel-pos gradient / read Delta from the tables
     if (dtype == PA_BF16 && head_dim == ATT_HD && attn2_ok(L, Hp, Wp))
         return attn2_bwd((const bf16*)qkv, ldq, (const bf16*)rcat, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, (bf16*)dqkv,
                          (bf16*)dG, aux, batch, L, heads, Hp, Wp, scale, st);

@@ -166,6 +166,29 @@ struct Epi4DGelu {
                make_float4(b.x * g2[0], b.y * g2[1], b.z * g3[0], b.w * g3[1]));
     }
 };
+// the same with the column sums of the stored dX (gemm256.h, epi_colsum): part f32 [2 * row tiles][N]
+struct Epi4DGeluCS : Epi4DGelu {
+    float* part;
+    DEVI void store_cs(int i, int j, float4 a, float4 b, const Col&, const Row& r, int, float (&cs)[8]) const {
+        if (i >= M || j >= N) return;
+        const uint4 w = r.p;
+        const float4 pa = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
+        const float4 pb = make_float4(bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w));
+        const f32x2_t g0 = gelu_grad_fast2(pa.x, pa.y), g1 = gelu_grad_fast2(pa.z, pa.w), g2 = gelu_grad_fast2(pb.x, pb.y), g3 = gelu_grad_fast2(pb.z, pb.w);
+        const uint4 pk = make_uint4(pack_bf16x2(a.x * g0[0], a.y * g0[1]), pack_bf16x2(a.z * g1[0], a.w * g1[1]),
+                                    pack_bf16x2(b.x * g2[0], b.y * g2[1]), pack_bf16x2(b.z * g3[0], b.w * g3[1]));
+        *reinterpret_cast<uint4*>(out + (size_t)i * ld + j) = pk;
+        cs[0] += bf16_lo(pk.x); cs[1] += bf16_hi(pk.x); cs[2] += bf16_lo(pk.y); cs[3] += bf16_hi(pk.y);        // the values as stored
+        cs[4] += bf16_lo(pk.z); cs[5] += bf16_hi(pk.z); cs[6] += bf16_lo(pk.w); cs[7] += bf16_hi(pk.w);
+    }
+    DEVI void colsum_out(int prow, int j, const float (&cs)[8]) const {
+        if (j >= N) return;
+        float* o = part + (size_t)prow * N + j;
+        *reinterpret_cast<float4*>(o) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+    }
+};
+template <> struct g256::epi_colsum<Epi4DGeluCS> { static constexpr bool value = true; };
 struct Epi4PixShuf {
     bf16* out; const float* bias; int Hp, Wp, P, C, M, N;
     typedef EpiCol8 Col;
@@ -385,25 +408,43 @@ extern "C" int pa_linear_pixshuf(int dtype, const void* x, int64_t ldx, const vo
 
 // ------------------------------------------------------------------------------- linear backward
 // dX[M,K] = dY[M,N] . W[N,K]      (contraction over N; W is contraction-major -> OpT)
+// dx_colsum (optional, needs `pre`): f32 [K] = column sums of dX as stored -- partial rows from the GEMM's epilogue on the bf16 fast
+// path (workspace), a separate pa_colsum pass otherwise
+extern "C" int64_t pa_linear_dgrad_workspace_bytes(int M, int K) {
+    const int64_t fast = (int64_t)2 * ((M + g256::BM_SHORT - 1) / g256::BM_SHORT) * K * sizeof(float);
+    const int64_t slow = pa_colsum_workspace_bytes(M, K);
+    return fast > slow ? fast : slow;
+}
 template <typename T>
-static int linear_dgrad_t(const T* dy, int64_t lddy, const T* w, const T* pre, T* dx, int64_t lddx, int M, int N, int K,
-                          hipStream_t st) {
+static int linear_dgrad_t(const T* dy, int64_t lddy, const T* w, const T* pre, T* dx, int64_t lddx, float* dx_colsum, float* ws, int M,
+                          int N, int K, hipStream_t st) {
     if constexpr (std::is_same<T, bf16>::value) {
         if (g256::ok(M, K, N, false, true, lddy, K)) {
+            if (pre && dx_colsum) {
+                Epi4DGeluCS ep;
+                ep.out = dx; ep.pre = pre; ep.ld = (size_t)lddx; ep.M = M; ep.N = K; ep.part = ws;
+                int e = g256::launch<false, true>(dy, lddy, w, K, ep, M, K, N, 1, st);
+                if (e) return e;
+                return pa_slab_reduce(ws, dx_colsum, K, 2 * g256::row_tiles_used(M, K, 1), K, 0, st);
+            }
             if (pre) return g256::launch<false, true>(dy, lddy, w, K, Epi4DGelu{dx, pre, (size_t)lddx, M, K}, M, K, N, 1, st);
             return g256::launch<false, true>(dy, lddy, w, K, Epi4Bias<bf16>{dx, (size_t)lddx, nullptr, M, K}, M, K, N, 1, st);
         }
     }
     OpN<T> A{dy, (size_t)lddy, M, 0};
     OpT<T> B{w, (size_t)K, K, 0};
-    if (pre) return launch_gemm<T, 2, 2>(A, B, EpiDGelu<T>{dx, pre, (size_t)lddx, M, K}, M, K, N, 1, 1, st);
-    return launch_gemm<T, 2, 2>(A, B, EpiBias<T>{dx, (size_t)lddx, nullptr, M, K}, M, K, N, 1, 1, st);
+    int e;
+    if (pre) e = launch_gemm<T, 2, 2>(A, B, EpiDGelu<T>{dx, pre, (size_t)lddx, M, K}, M, K, N, 1, 1, st);
+    else e = launch_gemm<T, 2, 2>(A, B, EpiBias<T>{dx, (size_t)lddx, nullptr, M, K}, M, K, N, 1, 1, st);
+    if (e || dx_colsum == nullptr) return e;
+    return pa_colsum(std::is_same<T, bf16>::value ? PA_BF16 : PA_F32, dx, lddx, M, K, dx_colsum, ws, st);
 }
 extern "C" int pa_linear_dgrad(int dtype, const void* dy, int64_t lddy, const void* w, const void* pre_for_dgelu,
-                               void* dx, int64_t lddx, int M, int N, int K, hipStream_t st) {
+                               void* dx, int64_t lddx, float* dx_colsum, void* workspace, int M, int N, int K, hipStream_t st) {
     if (N % 8 || K % 4) return (int)hipErrorInvalidValue;
-    if (dtype == PA_BF16) return linear_dgrad_t<bf16>((const bf16*)dy, lddy, (const bf16*)w, (const bf16*)pre_for_dgelu, (bf16*)dx, lddx, M, N, K, st);
-    return linear_dgrad_t<float>((const float*)dy, lddy, (const float*)w, (const float*)pre_for_dgelu, (float*)dx, lddx, M, N, K, st);
+    if (dx_colsum != nullptr && (workspace == nullptr || K % 8 || lddx % 8)) return (int)hipErrorInvalidValue;
+    if (dtype == PA_BF16) return linear_dgrad_t<bf16>((const bf16*)dy, lddy, (const bf16*)w, (const bf16*)pre_for_dgelu, (bf16*)dx, lddx, dx_colsum, (float*)workspace, M, N, K, st);
+    return linear_dgrad_t<float>((const float*)dy, lddy, (const float*)w, (const float*)pre_for_dgelu, (float*)dx, lddx, dx_colsum, (float*)workspace, M, N, K, st);
 }
 
 // dW[N,K] = dY[M,N]^T . X[M,K]    (contraction over M; both operands contraction-major), split-K + reduce

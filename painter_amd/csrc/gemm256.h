@@ -117,6 +117,11 @@ template <> struct Frag4<true> {
 //   Col col(j)                      per-lane column constants (bias[j..j+7]), loaded once per tile
 //   Row row(i, j)                   per-(row, 8 columns) global inputs (residual, GELU pre-activation), loaded ahead of the stores
 //   store(i, j, lo, hi, col, row, split)   lo = D[i][j..j+3], hi = D[i][j+4..j+7]
+// Optional column sums of the stored tile (epi_colsum<Epi>::value): the epilogue then calls store_cs(..., cs) instead of store(...), which
+// also adds the 8 values AS STORED to the lane's running column sums; after the tile the sums of the lanes that share columns are
+// combined (DPP / permlane, fixed order) and colsum_out(part_row, j, sums) writes one partial row per (row tile, wave row) -- the bias
+// gradient of the layer whose dY this GEMM's output is, without a separate pass over it (fc1: the fc2 data-gradient GEMM emits dpre).
+template <class Epi> struct epi_colsum { static constexpr bool value = false; };
 // ILV: how many of a phase's two LDS-DMA pieces are issued INSIDE the phase's MFMA segment instead of in front of its first barrier.
 // Between two barriers one wave row runs its MFMA segment (8 MFMAs = 256 cycles + the fragment wait) while the other runs its
 // load segment (fragment reads, 2 DMA issues at ~60-180 cycles each, the counted vmcnt wait); the barrier interval is the longer of
@@ -364,6 +369,7 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
         const int lr = lane & 31, g = lane >> 5, rrow = lane >> 3, c0 = (lane & 7) * 8;
         const int jcol = j0 + wc * 64 + c0;
         const typename Epi::Col col = epi.col(jcol);
+        float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             typename Epi::Row rows[2][4];
@@ -393,9 +399,23 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
                     const int r = st * 8 + rrow;
                     const float4 lo = *reinterpret_cast<const float4*>(stg + r * 68 + c0);
                     const float4 hi = *reinterpret_cast<const float4*>(stg + r * 68 + c0 + 4);
-                    epi.store(ib + r, jcol, lo, hi, col, rows[m2][st], split);
+                    if constexpr (epi_colsum<Epi>::value) epi.store_cs(ib + r, jcol, lo, hi, col, rows[m2][st], split, cs);
+                    else epi.store(ib + r, jcol, lo, hi, col, rows[m2][st], split);
                 }
             }
+        }
+        if constexpr (epi_colsum<Epi>::value) {
+            // the 8 lanes l, l + 8, ..., l + 56 hold the same 8 columns (other rows): rotate-by-8 inside a row of 16 lanes, then across
+            // rows with the permlane swaps; lanes 0..7 end up with the wave's sums and write the partial row of (row tile, wave row)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = cs[e];
+                v += lane_dpp<0x128>(v);
+                v += lane_xor16(v);
+                v += lane_xor32(v);
+                cs[e] = v;
+            }
+            if (lane < 8) epi.colsum_out(tm * 2 + wr, jcol, cs);
         }
     }
 }
@@ -456,6 +476,10 @@ static int launch_ilv(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi 
     PA_LAUNCH(kern, dim3(tiles_m * tiles_n, splits), dim3(NT), LDS_BYTES, st, A, (uint32_t)lda, B, (uint32_t)ldb, epi, M, N,
               ktiles, per, tiles_n, g_dbg[0], g_dbg[2]);
     return (int)hipGetLastError();
+}
+// row tiles of the launch launch<AMM = false>(...) makes for this shape (partial rows of a column-sum epilogue = 2 x this)
+static inline int row_tiles_used(int M, int N, int nsplit) {
+    return use_short(M, N, nsplit, false) ? (M + BM_SHORT - 1) / BM_SHORT : (M + BM - 1) / BM;
 }
 // shapes the kernel accepts; everything else stays on the generic engine (gemm_engine.h)
 static inline bool ok(int M, int N, int K, bool amm, bool bmm, size_t lda, size_t ldb) {

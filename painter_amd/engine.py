@@ -415,7 +415,9 @@ class HotPath:
             # ---- MLP branch: x2 = x1 + s_m * fc2(gelu(fc1(LN2(x1))))
             param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dyT, act, fl["fc2"])
             tr("%d.dyT" % i, dyT)
-            dpre = ops.linear_dgrad(dyT, self.w(pre + "mlp.fc2.weight", P), pre=hpre)
+            # (the GEMM's epilogue also sums the columns of the dpre it stores: fc1's bias gradient, no separate pass over [R, 4D])
+            dpre = ops.linear_dgrad(dyT, self.w(pre + "mlp.fc2.weight", P), pre=hpre, colsum_out=fl["fc1"])
+            G[pre + "mlp.fc1.bias"] = fl["fc1"]
             tr("%d.dpre" % i, dpre)
             param_grads(pre + "mlp.fc1.weight", pre + "mlp.fc1.bias", dpre, ln2, fl["fc1"])
             dln2 = ops.linear_dgrad(dpre, self.w(pre + "mlp.fc1.weight", P))

@@ -75,8 +75,10 @@ def linear_pixshuf(x, w, bias, batch, Hp, Wp, P, C):
     return out
 
 
-def linear_dgrad(dy, w, pre=None, out=None):
-    """dX[M,K] = dY[M,N] . W[N,K]  (* gelu'(pre) when pre is given)."""
+def linear_dgrad(dy, w, pre=None, out=None, colsum_out=None):
+    """dX[M,K] = dY[M,N] . W[N,K]  (* gelu'(pre) when pre is given).
+    colsum_out (f32 [K], optional): receives the column sums of dX as stored -- the bias gradient of the layer whose dY dX is -- from the
+    GEMM's epilogue (bf16 fast path) instead of a separate pass."""
     M, N = dy.shape
     K = w.shape[1]
     T = dy.dtype
@@ -85,7 +87,11 @@ def linear_dgrad(dy, w, pre=None, out=None):
         out = torch.empty((M, K), dtype=T, device=dy.device)
     if pre is not None:
         assert pre.stride(0) == out.stride(0)
-    check(lib.pa_linear_dgrad(code(T), p(dy), dy.stride(0), p(w), p(pre), p(out), out.stride(0), M, N, K, stream()),
+    ws = None
+    if colsum_out is not None:
+        assert colsum_out.shape == (K,) and colsum_out.dtype == torch.float32 and colsum_out.is_contiguous()
+        ws = workspace(lib.pa_linear_dgrad_workspace_bytes(M, K), dy.device, slot=2)
+    check(lib.pa_linear_dgrad(code(T), p(dy), dy.stride(0), p(w), p(pre), p(out), out.stride(0), p(colsum_out), p(ws), M, N, K, stream()),
           "pa_linear_dgrad")
     return out
 
@@ -190,9 +196,15 @@ def attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, sca
     T = qkv.dtype
     dev = qkv.device
     nrp, hd = rcat.shape
-    delta = torch.empty((batch * heads, L), dtype=torch.float32, device=dev)
-    check(lib.pa_attn_bwd_delta(code(T), p(out), out.stride(0), p(dout), dout.stride(0), p(delta), batch, L, heads, hd,
-                                stream()), "pa_attn_bwd_delta")
+    delta = None
+    if tables is not None and lib.pa_attn_bwd_prep_ok(code(T), L, Hp, Wp, hd):
+        # Delta = rowsum(dO o O) goes straight into the table tiles together with the log-sum-exp fields: one launch instead of two
+        check(lib.pa_attn_bwd_prep(code(T), p(out), out.stride(0), p(dout), dout.stride(0), p(lse), p(tables), batch, L, heads, Hp, Wp, hd,
+                                   float(scale), stream()), "pa_attn_bwd_prep")
+    else:
+        delta = torch.empty((batch * heads, L), dtype=torch.float32, device=dev)
+        check(lib.pa_attn_bwd_delta(code(T), p(out), out.stride(0), p(dout), dout.stride(0), p(delta), batch, L, heads, hd,
+                                    stream()), "pa_attn_bwd_delta")
     dqkv = torch.empty_like(qkv)
     nb = lib.pa_attn_bwd_relpos_partials_bytes(code(T), batch, L, heads, Hp, Wp, hd) if tables is not None else 0
     dG = part = None

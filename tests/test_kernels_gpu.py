@@ -138,6 +138,32 @@ def test_gemm256_224_row_tile_bit_identical_to_256_row_tile(M, N, K):
     assert relerr(ref[1], x.float() @ w.float().t() + b) < 2e-5 * math.sqrt(K)
 
 
+@pytest.mark.parametrize("M,N,K", [(12544, 1024, 4096), (1568, 1024, 1024), (500, 256, 264), (96, 128, 136)])
+@pytest.mark.parametrize("T", [torch.bfloat16, torch.float32])
+def test_linear_dgrad_column_sums_from_the_epilogue(T, M, N, K):
+    """pa_linear_dgrad(dx_colsum=...): the fc2 data-gradient GEMM dpre = (dY . W) * gelu'(pre) also returns the column sums of the dpre it
+    stores (= fc1's bias gradient; used to be a separate pa_colsum pass over [R, 4D]).  bf16 big shapes take the gemm256 epilogue
+    (both tile heights), the rest the generic engine + pa_colsum.  dX must be the bits of the call without the extra output; the sums
+    must equal a column sum of dX as stored (fp32 summation order aside)."""
+    dy, w, pre = gen((M, N), 6, 1.0, T), gen((N, K), 7, 0.05, T), gen((M, K), 9, 1.0, T)
+    ref = ops.linear_dgrad(dy, w, pre=pre)
+    from painter_amd._lib import lib
+    try:
+        for knob in (1, 2, 0):
+            lib.pa_debug_set(4, knob)
+            cs = torch.full((K,), float("nan"), device=DEV)
+            dx = ops.linear_dgrad(dy, w, pre=pre, colsum_out=cs)
+            assert torch.equal(dx, ref)
+            want = dx.double().sum(0)
+            assert relerr(cs, want) < 1e-5, (knob, relerr(cs, want))
+            assert relerr(cs, ops.colsum(dx)) < 1e-5
+            cs2 = torch.empty_like(cs)
+            ops.linear_dgrad(dy, w, pre=pre, colsum_out=cs2)
+            assert torch.equal(cs, cs2)                      # fixed reduction order: bit-stable
+    finally:
+        lib.pa_debug_set(4, 0)
+
+
 def _rel64(a, b):
     a, b = a.double(), b.double()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))

