@@ -451,7 +451,7 @@ extern "C" int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* 
 
 extern "C" int64_t pa_attn_bwd_aux_bytes(int batch, int L, int heads, int Hp, int Wp) {
     const int64_t gen1 = (int64_t)batch * heads * (L / 32) * (Hp + Wp + 2) * 32 * sizeof(float);
-    const int64_t gen2 = attn2_ok(L, Hp, Wp) ? attn2_aux_bytes(batch, L, heads, Hp, Wp) : 0;
+    const int64_t gen2 = (attn2_ok(L, Hp, Wp, 64) || attn2_ok(L, Hp, Wp, 80)) ? attn2_aux_bytes(batch, L, heads, Hp, Wp) : 0;
     return gen1 > gen2 ? gen1 : gen2;
 }
 
@@ -539,9 +539,9 @@ extern "C" int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* 
                          (float*)relpos_part, batch, L, heads, Hp, Wp, scale, st);
     }
     if (relpos_part != nullptr || dG == nullptr || delta == nullptr) return (int)hipErrorInvalidValue;      // only the generation-3 kernels fuse the rel-pos gradient / read Delta from the tables
-    if (dtype == PA_BF16 && head_dim == ATT_HD && attn2_ok(L, Hp, Wp))
+    if (dtype == PA_BF16 && attn2_ok(L, Hp, Wp, head_dim))
         return attn2_bwd((const bf16*)qkv, ldq, (const bf16*)rcat, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, (bf16*)dqkv,
-                         (bf16*)dG, aux, batch, L, heads, Hp, Wp, scale, st);
+                         (bf16*)dG, aux, batch, L, heads, Hp, Wp, head_dim, scale, st);
 #define PA_ATTN_BWD(TT_, HD_) attn_bwd_t<TT_, HD_>((const TT_*)qkv, ldq, (const TT_*)rcat, (const TT_*)rcatT, (const TT_*)dout, lddo, lse, delta, \
                                                    (TT_*)dqkv, (TT_*)dG, (float*)aux, batch, L, heads, Hp, Wp, scale, st)
     if (dtype == PA_BF16) return head_dim == 80 ? PA_ATTN_BWD(bf16, 80) : PA_ATTN_BWD(bf16, 64);

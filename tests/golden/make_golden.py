@@ -82,6 +82,10 @@ def grad_digest(named_grads, out: dict, prefix: str):
             # a strided sample of the tensor itself: unlike the norm / probe-dot digests (a random direction of the right norm
             # changes the probe dot by only ~1.4/sqrt(n) of the scale) this can tell a wrong gradient from a right one
             out[f"{prefix}grad_sample/{name}"] = g[::GRAD_STRIDE].clone().numpy()
+            # the rel-pos tables are short ([111, 64] / [55, 64]: 8 / 4 samples at stride 997) and the noisiest gradients of the bf16 build:
+            # they are stored whole as well, so that the test can take a relative Frobenius error over the full tensor (round 4)
+            if name.endswith("rel_pos_h") or name.endswith("rel_pos_w"):
+                out[f"{prefix}grad_full/{name}"] = g.clone().numpy()
     out[prefix + "grad_names"] = np.array(names)
     out[prefix + "grad_norm"] = np.array(norms, dtype=np.float64)
     out[prefix + "grad_sum"] = np.array(sums, dtype=np.float64)

@@ -345,12 +345,14 @@ def test_attn_bwd(T, B, H, Hp, Wp, gen_, attn_generation):
 
 
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("B,H,Hp,Wp", [(2, 2, 8, 4), (1, 3, 16, 8), (1, 2, 64, 32), (2, 1, 8, 12)])
+@pytest.mark.parametrize("B,H,Hp,Wp", [(2, 2, 8, 4), (1, 3, 16, 8), (1, 2, 64, 32), (2, 1, 8, 12), (1, 2, 8, 32), (2, 1, 16, 28), (1, 1, 4, 32)])
 def test_attn_head_dim_80_fwd_bwd(T, B, H, Hp, Wp):
-    """head_dim 80 (ViT-H/14, BASELINE configs[4]: 1280 / 16 heads; its token grid is 64 x 32): the generic kernels of attn_fwd.hip /
-    attn_bwd.hip instantiated for HD = 80 -- five 16-deep k-steps in Q.K^T / dO.V^T, three 32-row output blocks of which the last is
-    half padding -- forward (out, lse) and backward (dq, dk, dv, d rel_pos_h, d rel_pos_w) against the fp64 reference of
-    models_painter.py:76-86 + vitdet_utils.py:96-125.  Gates as for head_dim 64."""
+    """head_dim 80 (ViT-H/14, BASELINE configs[4]: 1280 / 16 heads; its token grid is 64 x 32): five 16-deep k-steps in Q.K^T / dO.V^T,
+    three 32-row output blocks of which the last is half padding -- forward (out, lse) and backward (dq, dk, dv, d rel_pos_h,
+    d rel_pos_w) against the fp64 reference of models_painter.py:76-86 + vitdet_utils.py:96-125.  Gates as for head_dim 64.
+    Kernels: bf16 with key rows of 12..28 or exactly 32 tokens -> the generation-2 kernels instantiated for HD = 80 (round 4:
+    csrc/attn2.hip over attn_tile_hd.h; key rows of 32 = one tile per key row, WP32); everything else (fp32; rows of 4 / 8 tokens) -> the
+    generic kernels of attn_fwd.hip / attn_bwd.hip."""
     hd = 80
     L = Hp * Wp
     nh, nw = 2 * Hp - 1, 2 * Wp - 1
