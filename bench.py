@@ -50,7 +50,7 @@ MODELS = {
     "vit_large": dict(factory="painter_vit_large_patch16_input896x448", blocks=FLOP_BLOCKS_FWD_BWD, whole=FLOP_MODEL_FWD_BWD, head_dim=64,
                       workload="painter_vit_large_patch16_input896x448 %s batch=%d/GPU fwd+bwd on %dxMI355X (BASELINE configs[1])"),
     "vit_huge": dict(factory="painter_vit_huge_patch14_input896x448", blocks=10.76e12, whole=11.66e12, head_dim=80,
-                     workload="painter_vit_huge_patch14_input896x448 %s batch=%d/GPU fwd+bwd on %dxMI355X (BASELINE configs[4]; untuned generic attention kernels)"),
+                     workload="painter_vit_huge_patch14_input896x448 %s batch=%d/GPU fwd+bwd on %dxMI355X (BASELINE configs[4]; head_dim 80 on the generation-2 attention kernels)"),
 }
 PEAK_BF16_TFLOPS = 2500.0          # dense MFMA peak (MI355X_MICROARCH.md)
 PEAK_F32_TFLOPS = 157.3
@@ -108,8 +108,8 @@ class KernelTimer:
         "gemm256_fwd": "g256::gemm256_kernel<false,false,*> (nn.Linear forward: qkv, proj, fc1+GELU, fc2, decoder_embed)",
         "gemm256_dgrad": "g256::gemm256_kernel<false,true,*> (nn.Linear data gradient dX = dY.W)",
         "gemm256_wgrad": "g256::gemm256_kernel<true,true,Epi4Slab> + slab_reduce (weight gradient dW = dY^T.X)",
-        "attention_fwd": "a3::fwd_kernel (fused attention forward, rel-pos bias on the matrix pipe; head_dim 80: attn_fwd_kernel<bf16,4,80>)",
-        "attention_bwd": "a3::bwd_dq_kernel + a3::bwd_dkv_kernel + delta/prep (fused attention backward, 2.5x the forward's FLOPs; head_dim 80: attn_bwd_dq/dkv_kernel<bf16,*,80>)",
+        "attention_fwd": "a3::fwd_kernel (fused attention forward, rel-pos bias on the matrix pipe; head_dim 80: a2::fwd_kernel<1,1,80>)",
+        "attention_bwd": "a3::bwd_dq_kernel (rel-pos table gradient contracted inside) + a3::bwd_dkv_kernel + prep_delta (fused attention backward, 2.5x the forward's FLOPs; head_dim 80: a2::bwd_dq_kernel<2,2,80,WP32> + a2::bwd_dkv_kernel<2,80> + delta)",
     }
 
     def __init__(self, ops_mod):

@@ -34,25 +34,41 @@ def build(cfg, seed, dtype, train=False):
     return m, P
 
 
-# gates on the sampled bf16 gradients of the fixtures (every 997th element of every tensor against the unmodified reference's fp32
-# gradient, max|a - b| / max|b| per tensor) = 1.5 x the largest value measured on MI355X (the tests print what they measure, pytest -s).
-# Measured, round 3 (largest over the round's builds): rel_pos_h / rel_pos_w tables 1.33e-1 (ViT-L B = 1), 1.04e-1 (B = 8) -- their gradient
-# is a sum of bf16-rounded per-query bias gradients over every query, head and sample, the noisiest tensors of the model; everything else
-# 2.2e-2 (ViT-L B = 1), 1.3e-2 (B = 8), 6.3e-2 (the head_dim-80 small model, whose tensors are short).
-BF16_SAMPLE_GATE = 1.0e-1          # every tensor except the rel-pos tables
-BF16_RELPOS_GATE = 2.0e-1
+# Gates on the bf16 build's gradients against the unmodified reference's fp32 gradients (the tests print what they measure, pytest -s).
+#  * every tensor except the rel-pos tables: every 997th element, max|a - b| / max|b| per tensor.  Measured on MI355X over rounds 3-4:
+#    <= 2.2e-2 at ViT-L (B = 1 and B = 8); gate 6e-2 (a dropped head or a mis-indexed tile moves a sampled tensor by >= 1/16).  The
+#    head_dim-80 small model has short tensors (few samples, larger spread: 4.0e-2 .. 6.3e-2 measured): gate 1e-1 there.
+#  * rel_pos_h / rel_pos_w ([111, 64] / [55, 64]): 8 / 4 samples at stride 997 say little, so since round 4 the fixtures carry these
+#    gradients WHOLE (grad_full/<name>) and the gate is the relative Frobenius error over the full tensor, 5e-2.  They are the noisiest
+#    gradients of the model for a structural reason, not a loose kernel: d rel_pos = sum over samples, heads and queries of class sums of
+#    dS = P o (dP - Delta), whose rows sum to zero -- the class sums are differences of nearly cancelling terms, and a bf16 build carries a
+#    2^-9 relative rounding on every P, dS and bias-table entry (the kernel-level error against fp64 on bf16-exact operands is 5e-3:
+#    tests/test_kernels_gpu.py).  The rounding of the per-query bias gradient dG that round 3 suspected is NOT the cause: with the
+#    gradient contracted inside the dQ kernel from fp32 partials (round 4) the error is unchanged to three digits.  The sampled rel-max
+#    stays as a coarse second check at 2e-1 (measured 8.4e-2 .. 1.3e-1 on 4-8 samples per tensor).
+BF16_SAMPLE_GATE = 6.0e-2          # every tensor except the rel-pos tables, ViT-L fixtures
+BF16_SAMPLE_GATE_SHORT = 1.0e-1    # the head_dim-80 small model
+BF16_RELPOS_FRO_GATE = 5.0e-2      # rel-pos tables: relative Frobenius error over the full tensor
+BF16_RELPOS_GATE = 2.0e-1          # rel-pos tables: sampled rel-max (coarse)
 
 
-def _check_bf16_samples(fx, case, m, tag, rtol_norm=1e-1, atol_dot=5e-2, small_rtol=1e-1):
+def _check_bf16_samples(fx, case, m, tag, rtol_norm=1e-1, atol_dot=5e-2, small_rtol=1e-1, sample_gate=BF16_SAMPLE_GATE):
     """bf16 build against a reference fixture: digests at the model-level bf16 bounds, the sampled gradients at the gates above."""
     rep = []
     G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], rtol_norm, atol_dot, small_rtol, sample_rtol=1e9, report=rep)
     rel = [r for r in rep if "rel_pos" in r[1]]
     oth = [r for r in rep if "rel_pos" not in r[1]]
-    print("%s: worst sampled-gradient rel-max error: rel-pos tables %.3e (%s), all other tensors %.3e (%s), %d tensors"
-          % ((tag,) + (max(rel) if rel else (0.0, "-")) + (max(oth) if oth else (0.0, "-")) + (len(rep),)))
+    fro = []
+    for n, p in m.named_parameters():
+        key = "%sgrad_full/%s" % (case, n)
+        if key in fx.files:
+            fro.append((G.rel_fro(p.grad.detach().float().cpu().reshape(-1), torch.as_tensor(fx[key]).reshape(-1)), n))
+    print("%s: worst sampled-gradient rel-max error: rel-pos tables %.3e (%s), all other tensors %.3e (%s), %d tensors; rel-pos tables, "
+          "full-tensor rel-Frobenius: worst %.3e (%s) over %d tables"
+          % ((tag,) + (max(rel) if rel else (0.0, "-")) + (max(oth) if oth else (0.0, "-")) + (len(rep),) + (max(fro) if fro else (0.0, "-")) + (len(fro),)))
     assert not rel or max(rel)[0] < BF16_RELPOS_GATE, max(rel)
-    assert not oth or max(oth)[0] < BF16_SAMPLE_GATE, max(oth)
+    assert not oth or max(oth)[0] < sample_gate, max(oth)
+    assert not fro or max(fro)[0] < BF16_RELPOS_FRO_GATE, max(fro)
 
 
 def run_painter(m, cfg, batch, seed_x, mask_kind, backward=True):
@@ -413,7 +429,7 @@ def test_h14_bf16_vs_reference_golden():
     ref_loss = float(fx[case + "loss"])
     assert abs(loss.item() - ref_loss) < 2e-3 * abs(ref_loss), (loss.item(), ref_loss)
     assert G.rel_fro(pred.cpu(), fx[case + "pred"]) < 3e-2
-    _check_bf16_samples(fx, case, m, "h14 bf16", 8e-2, 5e-2, 8e-2)
+    _check_bf16_samples(fx, case, m, "h14 bf16", 8e-2, 5e-2, 8e-2, sample_gate=BF16_SAMPLE_GATE_SHORT)
 
 
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
