@@ -58,7 +58,7 @@ int pa_linear_fwd(int dtype, int epilogue, const void* x /*T [M,K]*/, int64_t ld
 int pa_linear_pixshuf(int dtype, const void* x, int64_t ldx, const void* w /*T [P*P*C, K]*/, const float* bias,
                       void* out_nhwc, int batch, int Hp, int Wp, int P, int C, int K, hipStream_t stream);
 /* autograd of the above: dX = dY.W (optionally * gelu'(pre)), dW = dY^T.X (fp32), db = colsum(dY).
- * dx_colsum (optional, f32 [K], with workspace = pa_linear_dgrad_workspace_bytes(M, K)): the column sums of dX as stored -- dX is the dY
+ * dx_colsum (optional, f32 [K], with workspace = pa_linear_dgrad_workspace_bytes(M, K)): the column sums of dX (fp32, in front of its rounding to T on the bf16 fast path) -- dX is the dY
  * of the layer in front (fc1 behind the GELU), so this is that layer's bias gradient, taken in the GEMM's epilogue instead of a second
  * pass over dX. */
 int64_t pa_linear_dgrad_workspace_bytes(int M, int K);
@@ -79,12 +79,17 @@ int pa_layernorm_fwd(int dtype, const float* x, int64_t ldx, const float* gamma,
                      int R, int D, hipStream_t stream);
 int64_t pa_layernorm_bwd_workspace_bytes(int R, int D);
 /* dx = (dres ? dres : 0) + LN'(dy); dres may alias dx.  dxT (optional, T) = rowscale[row/rows_per_sample] * dx.
- * dgamma_dbeta: f32 [2, D], overwritten.  dxT_colsum (optional, f32 [D], needs dxT): the column sums of dxT as stored (rounded to
- * T) -- dxT is the dY of the nn.Linear in front of this norm's residual branch, so this is that layer's bias gradient, fused here. */
+ * dgamma_dbeta: f32 [2, D], overwritten.  dxT_colsum (optional, f32 [D], needs dxT): the column sums of rowscale * dx (the fp32 values
+ * dxT is rounded from) -- dxT is the dY of the nn.Linear in front of this norm's residual branch, so this is that layer's bias gradient, fused here. */
 int pa_layernorm_bwd(int dtype, const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,
                      const float* rstd, const float* gamma, const float* dres, float* dx, int64_t lddx, void* dxT,
                      int64_t lddxT, const float* rowscale, int rows_per_sample, float* dgamma_dbeta, float* dxT_colsum,
                      void* workspace, int R, int D, hipStream_t stream);
+/* Deferred form: pa_layernorm_bwd with dgamma_dbeta = NULL leaves the per-workgroup partial rows in `workspace` (dxT_colsum non-NULL there
+ * = "with column sums"; nothing is written through it); pa_layernorm_bwd_reduce finishes them -- nothing downstream in the backward reads
+ * these parameter gradients, so the engine runs the reduction on its side stream. */
+int pa_layernorm_bwd_reduce(const void* workspace, float* dgamma_dbeta, float* dxT_colsum, int with_colsum, int R, int D,
+                            hipStream_t stream);
 
 /* ---- Attention with decomposed rel-pos bias: models_painter.py:76-86 + util/vitdet_utils.py:63-125 ---- */
 int pa_relpos_rows_padded(int Hp, int Wp);

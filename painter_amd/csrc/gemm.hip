@@ -166,7 +166,7 @@ struct Epi4DGelu {
                make_float4(b.x * g2[0], b.y * g2[1], b.z * g3[0], b.w * g3[1]));
     }
 };
-// the same with the column sums of the stored dX (gemm256.h, epi_colsum): part f32 [2 * row tiles][N]
+// the same with the column sums of dX (the fp32 values in front of its bf16 rounding; gemm256.h, epi_colsum): part f32 [2 * row tiles][N]
 struct Epi4DGeluCS : Epi4DGelu {
     float* part;
     DEVI void store_cs(int i, int j, float4 a, float4 b, const Col&, const Row& r, int, float (&cs)[8]) const {
@@ -178,8 +178,8 @@ struct Epi4DGeluCS : Epi4DGelu {
         const uint4 pk = make_uint4(pack_bf16x2(a.x * g0[0], a.y * g0[1]), pack_bf16x2(a.z * g1[0], a.w * g1[1]),
                                     pack_bf16x2(b.x * g2[0], b.y * g2[1]), pack_bf16x2(b.z * g3[0], b.w * g3[1]));
         *reinterpret_cast<uint4*>(out + (size_t)i * ld + j) = pk;
-        cs[0] += bf16_lo(pk.x); cs[1] += bf16_hi(pk.x); cs[2] += bf16_lo(pk.y); cs[3] += bf16_hi(pk.y);        // the values as stored
-        cs[4] += bf16_lo(pk.z); cs[5] += bf16_hi(pk.z); cs[6] += bf16_lo(pk.w); cs[7] += bf16_hi(pk.w);
+        cs[0] = fmaf(a.x, g0[0], cs[0]); cs[1] = fmaf(a.y, g0[1], cs[1]); cs[2] = fmaf(a.z, g1[0], cs[2]); cs[3] = fmaf(a.w, g1[1], cs[3]);      // the fp32 values in front of the rounding
+        cs[4] = fmaf(b.x, g2[0], cs[4]); cs[5] = fmaf(b.y, g2[1], cs[5]); cs[6] = fmaf(b.z, g3[0], cs[6]); cs[7] = fmaf(b.w, g3[1], cs[7]);
     }
     DEVI void colsum_out(int prow, int j, const float (&cs)[8]) const {
         if (j >= N) return;

@@ -62,10 +62,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 }
 
 // dx_out = (dres ? dres : 0) + LNbwd(dy);  optional T copy dxT = rowscale[row / rps] * dx_out;
-// per-workgroup partial dgamma / dbeta -> part[block][NP][D], NP = 2, or 3 with CS: the third row is the column sum of dxT AS STORED
-// (rounded to T) = the bias gradient of the nn.Linear whose dY this dxT is (fc2 / proj) -- it used to be a separate pass over dxT
+// per-workgroup partial dgamma / dbeta -> part[block][NP][D], NP = 2, or 3 with CS: the third row is the column sum of rowscale * dx (the fp32
+// values dxT is rounded from) = the bias gradient of the nn.Linear whose dY this dxT is (fc2 / proj) -- it used to be a separate pass over dxT
+// (4 waves per SIMD: with the column-sum accumulators the kernel asked for 130 VGPRs = 3 waves per SIMD and ran 40 % slower, 69.6 vs 49.8 us
+// per ViT-L launch -- this HBM-bound stream needs the fourth wave to keep enough loads in flight)
 template <typename T, int NI, bool CS>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, size_t lddy, const float* __restrict__ x, size_t ldx,
+__global__ __launch_bounds__(256, NI <= 4 ? 4 : 2) void ln_bwd_kernel(const T* __restrict__ dy, size_t lddy, const float* __restrict__ x, size_t ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* dres, float* dx, size_t lddx,
                                                      T* dxT, size_t lddxT, const float* __restrict__ rowscale, int rps,
@@ -115,9 +117,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, s
                 }
                 *reinterpret_cast<float4*>(dx + (size_t)row * lddx + c) = o;
                 if (dxT) store4<T>(dxT + (size_t)row * lddxT + c, o.x * sc, o.y * sc, o.z * sc, o.w * sc);
-                if constexpr (CS) {          // what a column sum of dxT would read back: the values rounded to T
-                    ac[i].x += to_f(from_f<T>(o.x * sc)); ac[i].y += to_f(from_f<T>(o.y * sc));
-                    ac[i].z += to_f(from_f<T>(o.z * sc)); ac[i].w += to_f(from_f<T>(o.w * sc));
+                if constexpr (CS) {          // fp32 values in front of dxT's rounding (a round trip through T per element made the kernel VALU-heavier for nothing)
+                    ac[i].x = fmaf(o.x, sc, ac[i].x); ac[i].y = fmaf(o.y, sc, ac[i].y);
+                    ac[i].z = fmaf(o.z, sc, ac[i].z); ac[i].w = fmaf(o.w, sc, ac[i].w);
                 }
             }
         }
@@ -191,7 +193,7 @@ static int ln_bwd_t(const T* dy, int64_t lddy, const float* x, int64_t ldx, cons
     const int ni = (D + 255) / 256;
     const int nb = ln_bwd_blocks(R);
     dim3 grid(nb), blk(256);
-    const bool cs = dxT_colsum != nullptr;
+    const bool cs = dxT_colsum != nullptr;       // (with dgamma_dbeta == NULL: any non-NULL value selects the column-sum partials)
     if (cs && dxT == nullptr) return (int)hipErrorInvalidValue;
     const int np = cs ? 3 : 2;
     const size_t sm = (size_t)8 * D * sizeof(float);          // <= 64 KB for every D the kernel takes (NI <= 8: D <= 2048)
@@ -206,9 +208,15 @@ static int ln_bwd_t(const T* dy, int64_t lddy, const float* x, int64_t ldx, cons
 #undef LN_BWD
 #undef LN_BWD2
     int e = (int)hipGetLastError();
-    if (e) return e;
+    if (e || dgamma_dbeta == nullptr) return e;        // NULL: the caller reduces the partial rows later (pa_layernorm_bwd_reduce, e.g. on another stream)
     // partial rows are [dgamma | dbeta (| colsum)]: one reduction launch writes the first 2 D sums to dgamma_dbeta and the rest to dxT_colsum
     return pa_slab_reduce2(ws, dgamma_dbeta, dxT_colsum, 2 * D, np * D, nb, np * D, st);
+}
+// the reduction of pa_layernorm_bwd(dgamma_dbeta = NULL, ...)'s partial rows; with_colsum says whether that call was given a dxT_colsum
+extern "C" int pa_layernorm_bwd_reduce(const void* workspace, float* dgamma_dbeta, float* dxT_colsum, int with_colsum, int R, int D, hipStream_t st) {
+    if (workspace == nullptr || dgamma_dbeta == nullptr || (with_colsum && dxT_colsum == nullptr)) return (int)hipErrorInvalidValue;
+    const int np = with_colsum ? 3 : 2;
+    return pa_slab_reduce2((const float*)workspace, dgamma_dbeta, dxT_colsum, 2 * D, np * D, ln_bwd_blocks(R), np * D, st);
 }
 // dgamma_dbeta: [2, D] fp32 (dgamma then dbeta), overwritten.
 extern "C" int pa_layernorm_bwd(int dtype, const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,

@@ -425,8 +425,10 @@ class HotPath:
             del dpre
             # dyT may still be read by the side stream: the attention branch's dY gets its own buffer
             dyA = torch.empty_like(dyT) if side is not None else dyT
-            dx, gb = ops.layernorm_bwd(dln2, x1, mean2, rstd2, P[pre + "norm2.weight"], dres=dx, dx=dx, dxT=dyA,
-                                       rowscale=ds_a, rows_per_sample=L, gb=fl["n2"].view(2, D), dxT_colsum=fl["proj"])
+            # (the reduction of the LayerNorm parameter-gradient partials is a parameter gradient too: side stream)
+            dx, fin = ops.layernorm_bwd(dln2, x1, mean2, rstd2, P[pre + "norm2.weight"], dres=dx, dx=dx, dxT=dyA,
+                                        rowscale=ds_a, rows_per_sample=L, gb=fl["n2"].view(2, D), dxT_colsum=fl["proj"], defer=True)
+            gb = on_side(fin, fin.buffer)
             G[pre + "attn.proj.bias"] = fl["proj"]
             del dyT
             tr("%d.dx_ln2" % i, dx); tr("%d.dyA" % i, dyA); tr("%d.gb2" % i, gb)
@@ -456,9 +458,10 @@ class HotPath:
             if dyT_next is not None:               # dyT_next is block nxt's fc2 dY: its column sum goes into block nxt's flat buffer
                 cs_next = block_flat(nxt)[1]["fc2"]
                 G["blocks.%d.mlp.fc2.bias" % nxt] = cs_next
-            dx, gb = ops.layernorm_bwd(dln1, x0, mean1, rstd1, P[pre + "norm1.weight"], dres=dx, dx=dx, dxT=dyT_next,
-                                       rowscale=ds_next if dyT_next is not None else None, rows_per_sample=L, gb=fl["n1"].view(2, D),
-                                       dxT_colsum=cs_next)
+            dx, fin = ops.layernorm_bwd(dln1, x0, mean1, rstd1, P[pre + "norm1.weight"], dres=dx, dx=dx, dxT=dyT_next,
+                                        rowscale=ds_next if dyT_next is not None else None, rows_per_sample=L, gb=fl["n1"].view(2, D),
+                                        dxT_colsum=cs_next, defer=True)
+            gb = on_side(fin, fin.buffer)
             G[pre + "norm1.weight"], G[pre + "norm1.bias"] = gb[0], gb[1]
             tr("%d.dx_ln1" % i, dx)
             del x0, ln1, qkv, ao, x1, ln2, hpre, act, atab

@@ -132,23 +132,33 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype, out=None):
     return out, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, dx=None, dxT=None, rowscale=None, rows_per_sample=1, gb=None, dxT_colsum=None):
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, dx=None, dxT=None, rowscale=None, rows_per_sample=1, gb=None, dxT_colsum=None, defer=False):
     """-> dx (f32, = dres + LN'(dy)), dgamma_dbeta [2, D] (written into `gb` when given).
-    dxT_colsum (f32 [D], optional, needs dxT): receives the column sums of dxT as stored -- the bias gradient of the nn.Linear whose dY
-    dxT is -- from the same pass."""
+    dxT_colsum (f32 [D], optional, needs dxT): receives the column sums of rowscale * dx -- the bias gradient of the nn.Linear whose dY
+    dxT is -- from the same pass.
+    defer=True: -> (dx, finish): the parameter-gradient partial rows stay in a private buffer and `finish()` (callable once, on any stream
+    ordered behind this call) reduces them into gb / dxT_colsum and returns gb -- nothing downstream in the backward needs them."""
     R, D = x.shape
     if dx is None:
         dx = torch.empty((R, D), dtype=torch.float32, device=x.device)
     if gb is None:
         gb = torch.empty((2, D), dtype=torch.float32, device=x.device)
     assert gb.shape == (2, D) and gb.is_contiguous() and gb.dtype == torch.float32
-    ws = workspace(lib.pa_layernorm_bwd_workspace_bytes(R, D), x.device)
+    nbytes = lib.pa_layernorm_bwd_workspace_bytes(R, D)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device) if defer else workspace(nbytes, x.device)
     if dxT_colsum is not None:
         assert dxT is not None and dxT_colsum.shape == (D,) and dxT_colsum.dtype == torch.float32 and dxT_colsum.is_contiguous()
     check(lib.pa_layernorm_bwd(code(dy.dtype), p(dy), dy.stride(0), p(x), x.stride(0), p(mean), p(rstd), p(gamma),
                                p(dres), p(dx), dx.stride(0), p(dxT), 0 if dxT is None else dxT.stride(0), p(rowscale),
-                               rows_per_sample, p(gb), p(dxT_colsum), p(ws), R, D, stream()), "pa_layernorm_bwd")
-    return dx, gb
+                               rows_per_sample, 0 if defer else p(gb), p(dxT_colsum), p(ws), R, D, stream()), "pa_layernorm_bwd")
+    if not defer:
+        return dx, gb
+
+    def finish():
+        check(lib.pa_layernorm_bwd_reduce(p(ws), p(gb), p(dxT_colsum), int(dxT_colsum is not None), R, D, stream()), "pa_layernorm_bwd_reduce")
+        return gb
+    finish.buffer = ws
+    return dx, finish
 
 
 # ------------------------------------------------------------------------------------------- attention

@@ -154,9 +154,13 @@ def test_linear_dgrad_column_sums_from_the_epilogue(T, M, N, K):
             cs = torch.full((K,), float("nan"), device=DEV)
             dx = ops.linear_dgrad(dy, w, pre=pre, colsum_out=cs)
             assert torch.equal(dx, ref)
-            want = dx.double().sum(0)
-            assert relerr(cs, want) < 1e-5, (knob, relerr(cs, want))
-            assert relerr(cs, ops.colsum(dx)) < 1e-5
+            want = dx.double().sum(0)                         # dx is the ROUNDED copy of what the epilogue summed: bf16 rounding noise, averaged over M rows
+            tol = 1e-5 if T == torch.float32 else 4e-3
+            assert relerr(cs, want) < tol, (knob, relerr(cs, want))
+            assert relerr(cs, ops.colsum(dx)) < tol
+            pg = pre.double().clone().requires_grad_(True)
+            torch.nn.functional.gelu(pg).sum().backward()
+            assert relerr(cs, ((dy.double() @ w.double()) * pg.grad).sum(0)) < (2e-5 if T == torch.float32 else 2e-4)
             cs2 = torch.empty_like(cs)
             ops.linear_dgrad(dy, w, pre=pre, colsum_out=cs2)
             assert torch.equal(cs, cs2)                      # fixed reduction order: bit-stable
@@ -241,8 +245,9 @@ def test_layernorm_fwd_bwd(T, R, D):
     dxT = torch.empty((R, D), dtype=T, device=DEV)
     cs = torch.empty((D,), device=DEV)
     dx, gb = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres=dres, dxT=dxT, rowscale=rowscale, rows_per_sample=rps, dxT_colsum=cs)
-    # the fused bias gradient: column sums of dxT AS STORED (the same values a separate pa_colsum pass over dxT reads)
-    assert relerr(cs, dxT.double().sum(0)) < 1e-5 and relerr(cs, ops.colsum(dxT)) < 1e-5
+    # the fused bias gradient: column sums of rowscale * dx in fp32 (what dxT is rounded from; a pa_colsum pass over dxT sees the rounded values)
+    want_cs = ((dres.double() + xr.grad) * rowscale.repeat_interleave(rps)[:R, None].double()).sum(0)
+    assert relerr(cs, want_cs) < 2e-5 and relerr(cs, ops.colsum(dxT)) < (1e-5 if T == torch.float32 else 4e-3)
     dx_plain, gb_plain = ops.layernorm_bwd(dy, x, mean, rstd, gamma, dres=dres, dxT=torch.empty_like(dxT), rowscale=rowscale, rows_per_sample=rps)
     assert torch.equal(dx, dx_plain) and torch.equal(gb, gb_plain)            # the extra output changes nothing else
     ref = dres.double() + xr.grad

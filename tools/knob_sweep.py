@@ -42,7 +42,9 @@ def main():
 
     for _ in range(3):
         step()
-    settings = [("wgrad WGs %d" % n, 3, n) for n in (96, 128, 160, 192, 256)] + [("rel-pos splits %d" % s, 6, s) for s in (2, 4, 8)]
+    import os
+    wgs = [int(v) for v in os.environ.get("SWEEP_WGS", "96,128,160,192,256").split(",")]
+    settings = [("wgrad WGs %d" % n, 3, n) for n in wgs] + ([("rel-pos splits %d" % s, 6, s) for s in (2, 4, 8)] if "SWEEP_WGS" not in os.environ else [])
     res = {k: [] for k, _, _ in settings}
     for _ in range(rounds):
         for name, which, val in settings:
