@@ -520,25 +520,23 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
                 *reinterpret_cast<uint4*>(wimg + nimg * IMG + ql * 128 + (((2 * s + g) ^ rsw) << 4)) = __builtin_bit_cast(uint4, qf[s]);
         }
         __syncthreads();
+        // 2 * NRP / 32 units (r-block, d-block) of one 32 x 32 accumulator over the workgroup's query blocks; wave w takes units w, w + 4, ...
+        // Orientation: A = dG^T (rows r -> registers), B = Q^T (lanes = d), so that a store instruction writes 32 consecutive d of one row:
+        // two 128-byte segments per instruction (the first form had lane = r: 64 rows, 16 bytes each, per instruction).
         float* pw = part + (size_t)(pslot0 + blockIdx.x) * NRP * ATT_HD;
-        for (int rb = wave; rb < NRP / 32; rb += NW) {
-            f32x16 acc[2] = {zero16(), zero16()};
+        for (int u = wave; u < 2 * (NRP / 32); u += NW) {
+            const int rb = u >> 1, db = u & 1;
+            f32x16 acc = zero16();
             for (int w2 = 0; w2 < NW; ++w2) {
                 if ((tile0 + blk * NW + w2) * 32 >= L) break;         // that wave had no queries
                 const unsigned char* im = smem + w2 * (nimg + 1) * IMG;
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const bf16x8 gt = trfrag(im + (rb >> 1) * IMG, la, rb & 1, ks);      // B: lane = r, slots = q
-#pragma unroll
-                    for (int db = 0; db < 2; ++db) acc[db] = mfma(trfrag(im + nimg * IMG, la, db, ks), gt, acc[db]);
-                }
+                for (int ks = 0; ks < 2; ++ks)
+                    acc = mfma(trfrag(im + (rb >> 1) * IMG, la, rb & 1, ks), trfrag(im + nimg * IMG, la, db, ks), acc);
             }
-            float* prow = pw + (size_t)(rb * 32 + ql) * ATT_HD + 4 * g;                   // D: lane = r, registers = d
+            float* pcol = pw + (size_t)(rb * 32 + 4 * g) * ATT_HD + db * 32 + ql;          // D: registers = r, lane = d
 #pragma unroll
-            for (int db = 0; db < 2; ++db)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg)
-                    *reinterpret_cast<float4*>(prow + db * 32 + 8 * rg) = make_float4(acc[db][rg * 4], acc[db][rg * 4 + 1], acc[db][rg * 4 + 2], acc[db][rg * 4 + 3]);
+            for (int reg = 0; reg < 16; ++reg) pcol[((reg & 3) + 8 * (reg >> 2)) * ATT_HD] = acc[reg];
         }
     }
     if constexpr (TR) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }

@@ -29,6 +29,7 @@ _DBG_TRACE = os.environ.get("PAINTER_AMD_DEBUG_TRACE", "0") == "1"     # checksu
 
 
 _SIDE_STREAM = os.environ.get("PAINTER_AMD_SIDE_STREAM", "1") != "0"
+_SIDE_PRIORITY = int(os.environ.get("PAINTER_AMD_SIDE_PRIORITY", "0"))
 _configured = False
 # sizing of the parameter-gradient kernels when they run on the side stream, beside the data-gradient chain (0 = stand-alone sizing)
 WGRAD_SIDE_TARGET = 128
@@ -119,7 +120,9 @@ class HotPath:
     def side_stream(self, device):
         s = self._side.get(device)
         if s is None:
-            s = torch.cuda.Stream(device=device)
+            # PAINTER_AMD_SIDE_PRIORITY: HIP stream priority of the parameter-gradient stream (0 = default; what the runtime accepts
+            # is clamped by torch / HIP; tools/prio_ab.py measures it against a high-priority main stream)
+            s = torch.cuda.Stream(device=device, priority=getattr(self, "side_priority", _SIDE_PRIORITY))
             self._side[device] = s
         return s
 
