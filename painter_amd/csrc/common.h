@@ -157,7 +157,7 @@ DEVI float gelu_grad_fast(float x) {
     return fmaf(x * 0.39894228040143268f, e, c);
 }
 
-// Two elements at once for the gemm256 / gemm128 epilogues, where the GELU is 33 us of the 154 us fc1 launch with the matrix pipe idle
+// Two elements at once for the gemm256 epilogues, where the GELU is 33 us of the 154 us fc1 launch with the matrix pipe idle
 // (tools/fc1_epilogue.py): the same A-S polynomial on float2 values -- hipcc emits v_pk_mul / v_pk_fma / v_pk_add_f32 for these, half
 // the issue slots of the scalar form -- with the constants folded (0.5 into the coefficients, 1/sqrt2 into the rcp argument) and the
 // sign handled by copysign instead of compare + select.  Packed fp32 arithmetic is bit-identical to scalar, alone and beside MFMA

@@ -1,5 +1,6 @@
 """What does the fc1 epilogue cost?  The fc1 shape (12544 x 4096 x 1024) with: bias only (one bf16 store), bias + GELU (one store),
-bias + GELU + pre-activation (two stores, the training forward), for both tile shapes.  Diagnostics."""
+bias + GELU + pre-activation (two stores, the training forward), for both row-tile heights of gemm256 (pa_debug_set(4, 1 | 2): 256 rows = 784
+tiles in 3.06 rounds, 224 rows = 896 tiles in 3.5 rounds).  Diagnostics."""
 import sys
 
 import torch
@@ -22,7 +23,7 @@ def main():
     cases = [("bias, one store", lambda: ops.linear_fwd(x1, w, b, EPI_BIAS, out=a)),
              ("bias + GELU, one store", lambda: ops.linear_fwd(x1, w, b, EPI_BIAS_GELU, out=a, out2=None)),
              ("bias + GELU, two stores", lambda: ops.linear_fwd(x1, w, b, EPI_BIAS_GELU, out=a, out2=pre))]
-    for mode, kname in ((0, "gemm256"), (1, "gemm128")):
+    for mode, kname in ((0, "256-row tile"), (1, "224-row tile")):
         for name, fn in cases:
             res = []
             for rep in range(3):
