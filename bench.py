@@ -29,6 +29,9 @@ all-reduce (RCCL, bucketed, overlapped with backward) is inside the step.  Print
                  /root/reference, or on the GPU box from the subset oracle/stage_ref.py staged at build time; kind "port" = the restated
                  oracle/painter_oracle.py when neither exists) on the host cores, B = 1, fp32, thread count swept over {16, 32, 64, all
                  physical cores}: value = train forward+backward images/sec at the best count, the all-cores figure beside it.
+  reference_gpu = the same unmodified reference model on THIS GPU through PyTorch-ROCm eager (autocast bf16, and fp16 -- the reference's
+                 literal torch.cuda.amp.autocast() -- beside it), B = 8, the bench model's parameters and batch, train forward+backward;
+                 vs_reference_gpu = value / that.  A baseline leg outside every timed region of the headline number (N = 1 only).
 """
 import argparse
 import json
@@ -235,6 +238,51 @@ def cpu_baseline(budget_s=100.0):
                       % (warm, counts, best, ["%.2f" % t for t in sweep[best]], ["%.2f" % t for t in tes], best, phys, 1.0 / sweep[phys][0])}
 
 
+def reference_gpu_baseline(model, inputs, dev, steps=5, warmup=2):
+    """The UNMODIFIED reference model on THIS GPU through PyTorch-ROCm's own kernels (rocBLAS / hipBLASLt / ATen), driven as
+    Painter/engine_train.py:56-75 drives it: forward under autocast, loss.backward().  Same factory, same parameters (copied from the
+    bench model: the module trees have the same names), same synthetic batch, train mode.  The reference's literal autocast dtype is
+    fp16 (torch.cuda.amp.autocast() + loss scaler); bf16 -- the dtype of the measured path -- is the primary figure, fp16 is reported
+    beside it.  Baseline only: nothing of it runs inside the timed region of the headline number.  None when the reference sources
+    (or the subset oracle/stage_ref.py staged at build time) are not available."""
+    from oracle import ref_import
+    if not ref_import.reference_available():
+        return None
+    ref = ref_import.load_reference_painter()
+    rmodel = ref.painter_vit_large_patch16_input896x448_win_dec64_8glb_sl1()
+    rmodel.load_state_dict({k: v.detach().float().cpu() for k, v in model.state_dict().items()}, strict=True)
+    rmodel = rmodel.to(dev).train()
+    imgs, tgts, mask, valid = inputs
+    res = {}
+    for name, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):
+        def step():
+            rmodel.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=dt):
+                loss, _, _ = rmodel(imgs, tgts, mask, valid.clone())
+            loss.backward()
+            return loss
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(steps):
+            loss = step()
+        torch.cuda.synchronize()
+        ms = (time.time() - t0) / steps * 1e3
+        res[name] = (ms, float(loss.detach().float()))
+    peak_mem = torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    del rmodel
+    torch.cuda.empty_cache()
+    B = imgs.shape[0]
+    return {"value": round(B / res["bf16"][0] * 1e3, 2), "unit": "images/sec", "ms_per_step": round(res["bf16"][0], 2), "dtype": "bf16 autocast",
+            "fp16_autocast_value": round(B / res["fp16"][0] * 1e3, 2), "fp16_autocast_ms_per_step": round(res["fp16"][0], 2),
+            "kind": "reference", "steps": steps, "warmup": warmup, "loss_bf16": round(res["bf16"][1], 6),
+            "peak_memory_gib_process": round(peak_mem, 1),
+            "sample": "the unmodified reference Painter (models_painter.py:464-487 via oracle/ref_import.py) on this GPU, PyTorch %s eager, "
+                      "autocast + loss.backward() as engine_train.py:56-75, ViT-L 896x448, B=%d, train mode, the bench model's parameters and "
+                      "batch; %d warm-up + %d timed steps, host clock around a device synchronize" % (torch.__version__, B, warmup, steps)}
+
+
 def optimizer_step_ms(model, step_fn):
     """Reported next to the headline number, never inside it ("+ optimizer step reported separately"):
     the fused unscale + clip(3.0) + AdamW of painter_amd/optim.py (52 layer-decay groups as util/lr_decay.py builds them) vs
@@ -382,6 +430,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--profile-steps", type=int, default=2, help="steps of the separate, event-instrumented pass after the timed region (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-gpu", action="store_true", help="skip the reference-on-this-GPU leg (unmodified reference model, PyTorch eager)")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--eval", action="store_true", help="eval mode (no DropPath)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -572,6 +621,15 @@ def main():
             out["optimizer_step"] = optimizer_step_ms(model, step)
         if n_ranks == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        if n_ranks == 1 and not args.no_reference_gpu and args.model == "vit_large" and not args.eval:
+            try:
+                rg = reference_gpu_baseline(model, (imgs, tgts, mask, valid), dev)
+            except Exception as e:                      # a baseline leg never takes the line down
+                rg = {"error": "%s: %s" % (type(e).__name__, e)}
+            if rg is not None:
+                out["reference_gpu"] = rg
+                if "value" in rg:
+                    out["vs_reference_gpu"] = round(out["value"] / rg["value"], 2)
         print(json.dumps(out), flush=True)
     if distributed:
         torch.distributed.barrier()
