@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--prompts", type=int, default=32)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--no-reference-gpu", action="store_true")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     N = args.prompts
@@ -64,11 +65,42 @@ def main():
     t_graph = (time.perf_counter() - t0) / args.iters
     same = bool(torch.equal(g_pred, ref_pred))
     flop = N * 1.5897e12
+    # the unmodified reference model (SegGPT_inference/models_seggpt.py through oracle/ref_import.py) on this GPU, PyTorch-ROCm eager: fp32 as
+    # seggpt_engine.py:36-47 calls it (no autocast), and under bf16 autocast -- same parameters, same batch.  Baseline only.
+    reference_gpu = None
+    try:
+        from oracle import ref_import
+        if ref_import.reference_available() and not args.no_reference_gpu:
+            rmod = ref_import.load_reference_seggpt().seggpt_vit_large_patch16_input896x448()
+            rmod.load_state_dict({k: v.detach().float().cpu() for k, v in m.state_dict().items()}, strict=True)
+            rmod = rmod.to(dev).eval()
+            res = {}
+            for name, ctx in (("fp32", None), ("bf16_autocast", torch.bfloat16)):
+                def rfwd():
+                    with torch.no_grad():
+                        if ctx is None:
+                            return rmod(imgs, tgts, mask, valid, seg_type, 0)
+                        with torch.autocast("cuda", dtype=ctx):
+                            return rmod(imgs, tgts, mask, valid, seg_type, 0)
+                rfwd()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    rl, rp, _ = rfwd()
+                torch.cuda.synchronize()
+                res[name] = ((time.perf_counter() - t0) / 3, float(rl.item()))
+            reference_gpu = {"fp32_ms": round(res["fp32"][0] * 1e3, 2), "fp32_images_per_sec": round(N / res["fp32"][0], 2),
+                             "bf16_autocast_ms": round(res["bf16_autocast"][0] * 1e3, 2),
+                             "bf16_autocast_images_per_sec": round(N / res["bf16_autocast"][0], 2), "loss_fp32": res["fp32"][1],
+                             "torch": torch.__version__}
+            del rmod
+    except Exception as e:
+        reference_gpu = {"error": "%s: %s" % (type(e).__name__, e)}
     print(json.dumps({
         "metric": "images/sec (896x448 pairs) SegGPT ViT-L forward, N prompts + feature ensemble", "prompts": N, "dtype": "bf16",
         "eager_ms": round(t_eager * 1e3, 3), "eager_images_per_sec": round(N / t_eager, 2),
         "hipgraph_ms": round(t_graph * 1e3, 3), "hipgraph_images_per_sec": round(N / t_graph, 2),
-        "tflops_hipgraph": round(flop / t_graph / 1e12, 1), "replay_equals_eager": same, "loss": ref_loss}))
+        "tflops_hipgraph": round(flop / t_graph / 1e12, 1), "replay_equals_eager": same, "loss": ref_loss, "reference_gpu": reference_gpu}))
 
 
 if __name__ == "__main__":
