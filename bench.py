@@ -238,7 +238,7 @@ def cpu_baseline(budget_s=100.0):
                       % (warm, counts, best, ["%.2f" % t for t in sweep[best]], ["%.2f" % t for t in tes], best, phys, 1.0 / sweep[phys][0])}
 
 
-def reference_gpu_baseline(model, inputs, dev, steps=5, warmup=2):
+def reference_gpu_baseline(model, inputs, dev, steps=5, warmup=2, train=True):
     """The UNMODIFIED reference model on THIS GPU through PyTorch-ROCm's own kernels (rocBLAS / hipBLASLt / ATen), driven as
     Painter/engine_train.py:56-75 drives it: forward under autocast, loss.backward().  Same factory, same parameters (copied from the
     bench model: the module trees have the same names), same synthetic batch, train mode.  The reference's literal autocast dtype is
@@ -251,7 +251,7 @@ def reference_gpu_baseline(model, inputs, dev, steps=5, warmup=2):
     ref = ref_import.load_reference_painter()
     rmodel = ref.painter_vit_large_patch16_input896x448_win_dec64_8glb_sl1()
     rmodel.load_state_dict({k: v.detach().float().cpu() for k, v in model.state_dict().items()}, strict=True)
-    rmodel = rmodel.to(dev).train()
+    rmodel = rmodel.to(dev).train(train)
     imgs, tgts, mask, valid = inputs
     res = {}
     for name, dt in (("bf16", torch.bfloat16), ("fp16", torch.float16)):

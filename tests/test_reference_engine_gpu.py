@@ -77,3 +77,24 @@ def test_reference_run_one_image_drives_the_hip_seggpt_module():
     y = O.unpatchify(yo, cfg.patch_size).permute(0, 2, 3, 1)
     ref = torch.clip((y[0, y.shape[1] // 2:] * torch.tensor(O.IMAGENET_STD) + torch.tensor(O.IMAGENET_MEAN)) * 255, 0, 255)
     assert out.shape == ref.shape and float((out - ref).abs().max()) < 0.05
+
+
+def test_bench_reference_gpu_leg_times_the_unmodified_model_and_agrees_with_the_hip_path():
+    """bench.py's `reference_gpu` leg (the unmodified reference ViT-L through PyTorch-ROCm eager on this GPU, the bench model's parameters
+    and batch): it must run (bf16 and fp16 autocast), and -- in eval mode, where DropPath draws nothing -- the loss it reports under
+    bf16 autocast must be the loss of the measured path on the same batch (both bf16: 2e-3, the gate of the bf16 parity tests)."""
+    import bench
+    from painter_amd import models_painter
+    dev = torch.device("cuda", 0)
+    model = models_painter.painter_vit_large_patch16_input896x448_win_dec64_8glb_sl1(compute_dtype="bf16")
+    bench.randomize_parameters(model, seed=1)
+    model = model.to(dev).eval()
+    c = model._cfg
+    inputs = bench.synthetic_inputs(1, c.H, c.W, c.L, 77, dev)
+    with torch.no_grad():
+        ours = float(model(inputs[0], inputs[1], bool_masked_pos=inputs[2], valid=inputs[3].clone())[0])
+    rg = bench.reference_gpu_baseline(model, inputs, dev, steps=1, warmup=1, train=False)
+    assert rg is not None and rg["kind"] == "reference" and rg["value"] > 0 and rg["fp16_autocast_value"] > 0
+    print("reference on this GPU, B=1 eval-mode parameters: %.1f images/s (bf16 autocast); loss %.6f vs the HIP path %.6f"
+          % (rg["value"], rg["loss_bf16"], ours))
+    assert abs(rg["loss_bf16"] - ours) <= 2e-3 * abs(ours), (rg["loss_bf16"], ours)
