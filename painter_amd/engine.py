@@ -212,6 +212,7 @@ class HotPath:
         S.B, S.need_grad = B, need_grad
         S.imgs, S.tgts, S.mask, S.valid = imgs, tgts, mask_u8, valid
         S.drop = drop_scales
+        S.seg_type = seg_type if c.seggpt else None
         pe = P["pos_embed"][0, c.cls:]
         pos = ops.pos_fwd(self.pos_operator(dev)[0], pe, L, D)
         tok_args = (P["patch_embed.proj.bias"], P["mask_token"], P["segment_token_x"], P["segment_token_y"], pos, mask_u8,
@@ -240,9 +241,16 @@ class HotPath:
             rcat = self.relpos(pre, P, False)
             ao, lse, atab = ops.attn_fwd(qkv, rcat, Bc, L, c.heads, c.Hp, c.Wp, c.scale, need_tables=True) if need_grad else \
                 ops.attn_fwd(qkv, rcat, Bc, L, c.heads, c.Hp, c.Wp, c.scale) + (None,)
+            group = 0
             if merge > 0:
-                if need_grad:
-                    raise NotImplementedError("SegGPT feature ensemble is inference-only (as in the reference: @torch.no_grad, seggpt_engine.py:26)")
+                # Differentiable like the reference's Block.forward (models_seggpt.py:207-238) as long as no DropPath factor sits between the
+                # ensemble and the residual add (eval mode, or drop_path_rate 0): mean-over-the-group + broadcast is its own adjoint, the
+                # backward applies the same operator to the branch gradient.  The reference itself only runs it under @torch.no_grad
+                # (seggpt_engine.py:26); with DropPath draws (train mode) the scaled form is not built.
+                if need_grad and ds_a is not None:
+                    raise NotImplementedError("SegGPT feature ensemble under autograd needs eval mode or drop_path_rate = 0 "
+                                              "(the DropPath-scaled ensemble backward is not built; the reference runs the ensemble under "
+                                              "@torch.no_grad, seggpt_engine.py:26)")
                 a = ops.linear_fwd(ao, self.w(pre + "attn.proj.weight", P), P[pre + "attn.proj.bias"], EPI_BIAS_F32)
                 group = Bc // 2 if merge == 1 else Bc
                 x1 = ops.ensemble_resid(x, a, Bc, group, L, D)
@@ -254,7 +262,7 @@ class HotPath:
             x2 = ops.linear_fwd(act, self.w(pre + "mlp.fc2.weight", P), P[pre + "mlp.fc2.bias"], EPI_BIAS_RESID,
                                 resid=x1, rowscale=ds_m, rows_per_sample=L)
             if need_grad:
-                S.blocks.append((x, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc, atab))
+                S.blocks.append((x, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc, atab, group))
             x = x2
             if i == c.merge_idx:
                 Bc = B
@@ -390,7 +398,7 @@ class HotPath:
         rc_shape = tuple(S.blocks[-1][5].shape)            # Rcat [NRP, head_dim]: the same for every block
         for i in reversed(range(c.depth)):
             pre = "blocks.%d." % i
-            x0, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc, atab = S.blocks[i]
+            x0, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc, atab, ens_group = S.blocks[i]
             S.blocks[i] = None
             R = Bc * L
             ds_a, ds_m = (None, None) if S.drop is None else S.drop[i]
@@ -437,6 +445,13 @@ class HotPath:
             tr("%d.dx_ln2" % i, dx); tr("%d.dyA" % i, dyA); tr("%d.gb2" % i, gb)
             G[pre + "norm2.weight"], G[pre + "norm2.bias"] = gb[0], gb[1]
             # ---- attention branch: x1 = x0 + s_a * proj(attn(LN1(x0)))
+            if ens_group > 0:
+                # SegGPT feature ensemble (forward: x1 = x0 + ens(proj(...)), no DropPath factor): the branch gradient is ens applied to
+                # dx (fp32: the kernel's own type), re-rounded to the operand type.  Column sums are unchanged by a mean + broadcast over
+                # samples, so the proj bias gradient the LayerNorm backward already summed stands.
+                da = ops.ensemble_resid(torch.zeros_like(dx), dx, Bc, ens_group, L, D)
+                dyA = da if T == torch.float32 else ops.cast_bf16(da, out=dyA)
+                del da
             param_grads(pre + "attn.proj.weight", pre + "attn.proj.bias", dyA, ao, fl["proj"])
             dao = ops.linear_dgrad(dyA, self.w(pre + "attn.proj.weight", P), out=dln2)
             tr("%d.dao" % i, dao)
@@ -483,8 +498,18 @@ class HotPath:
         G["segment_token_x"] = ops.colsum(sums[0]).view(1, 1, 1, D)
         G["segment_token_y"] = ops.colsum(sums[1]).view(1, 1, 1, D)
         G["mask_token"] = ops.colsum(sums[2]).view(1, 1, 1, D)
+        small_tail = []
+        if c.seggpt and S.seg_type is not None:
+            # SegGPT's two segmentation-type tokens (models_seggpt.py:415-420: added to every token of both streams of the samples of their
+            # type): gradient = sum of dx over those samples' rows -- per-sample row weights (1 where the type matches) through the
+            # row-scale kernel, then a column sum.  Only reached when a SegGPT module is differentiated (the reference never does).
+            for t_, nm in ((0.0, "type_token_cls"), (1.0, "type_token_ins")):
+                w = (S.seg_type.reshape(-1) == t_).to(torch.float32)
+                sel = ops.scale_cast(torch.float32, dx, torch.cat((w, w)).contiguous(), L)
+                G[nm] = ops.colsum(sel).view(1, 1, 1, D)
+                small_tail.append(nm)
         ready(["norm.weight", "norm.bias", "patch_embed.proj.weight", "patch_embed.proj.bias", "pos_embed",
-               "segment_token_x", "segment_token_y", "mask_token"])
+               "segment_token_x", "segment_token_y", "mask_token"] + small_tail)
         if side is not None:
             if getattr(self, "tail_probe", None) is not None:      # diagnostics (tools/step_tail.py): when each stream ran dry
                 self.tail_probe[0].record(main)

@@ -2,8 +2,9 @@
 
 `SegGPT` = the Painter network + two segmentation-type tokens (models_seggpt.py:285-286, :415-420), the cross-prompt
 feature ensemble inside each block (`Block.forward(x, merge)`, :220-232, schedule :426-429) and the loss without the
-ignore rule (:448-469).  Forward runs entirely in libpainter_hip.so; like the reference (seggpt_engine.py:26,
-@torch.no_grad) the ensemble path is inference-only.
+ignore rule (:448-469).  Forward and backward run entirely in libpainter_hip.so.  The reference only ever runs the ensemble under
+@torch.no_grad (seggpt_engine.py:26); it is differentiable here too in eval mode / with drop_path_rate 0 (no DropPath factor between
+the ensemble and the residual add; engine.py), and refuses in train mode.
 """
 from functools import partial
 

@@ -157,6 +157,49 @@ def test_small_seggpt_inference_vs_reference_golden(case, n, merge, seg, seed_x)
     assert mo.shape == (1, L) and mo.dtype == torch.bool
 
 
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("n,merge", [(4, 0), (3, 1)])
+def test_small_seggpt_feature_ensemble_under_autograd_vs_oracle(dtype, n, merge):
+    """The SegGPT feature ensemble (Block.forward(x, merge), models_seggpt.py:207-238: query-half tokens of the attention branch are
+    averaged over the prompts, per stream half before the early merge and over all prompts after it) is differentiable in the
+    reference, which only ever runs it under no_grad.  Here: eval mode (no DropPath factor between the ensemble and the residual add),
+    loss.backward() through the HIP path against the oracle's autograd on the same parameters and batch -- every parameter gradient.
+    Train mode (DropPath draws) still refuses, with a message."""
+    cfg = O.small_config(seggpt=True)
+    m, P = build(cfg, 17, dtype)
+    imgs, tgts, _, valid = O.synthetic_batch(cfg, n, 31, "half")
+    L = cfg.grid[0] * cfg.grid[1]
+    mask = torch.zeros(1, L)
+    mask[:, L // 2:] = 1
+    seg_type = torch.ones(n, 1)
+    seg_type[0] = 0                                      # both segmentation-type tokens get a gradient
+    loss, pred, _ = m(imgs.cuda(), tgts.cuda(), mask.cuda(), valid.clone().cuda(), seg_type.cuda(), merge)
+    loss.backward()
+    Po = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lo, _, _ = O.forward(Po, cfg, imgs, tgts, mask.bool().expand(n, L), valid.clone(), seg_type, merge)
+    lo.backward()
+    tol_l, tol_g = (1e-4, 2e-3) if dtype == "fp32" else (3e-3, 1e-1)
+    assert abs(loss.item() - lo.item()) < tol_l * abs(lo.item()), (loss.item(), lo.item())
+    worst = ("", 0.0)
+    for name, p in m.named_parameters():
+        go = Po[name].grad
+        if p.grad is None or go is None:              # an unused parameter (the other segmentation-type token): None here, None or zeros there
+            assert (go is None or float(go.abs().max()) == 0.0) and (p.grad is None or float(p.grad.abs().max()) == 0.0), name
+            continue
+        den = float(go.abs().max())
+        if den == 0.0:
+            assert float(p.grad.abs().max()) == 0.0, name
+            continue
+        e = float((p.grad.cpu().reshape(go.shape) - go).abs().max()) / den
+        if e > worst[1]:
+            worst = (name, e)
+    print("ensemble under autograd, %s, n=%d merge=%d: loss %.6f vs oracle %.6f, worst gradient %s %.2e" % ((dtype, n, merge, loss.item(), lo.item()) + worst))
+    assert worst[1] < tol_g, worst
+    m.train()
+    with pytest.raises(NotImplementedError, match="eval mode"):
+        m(imgs.cuda(), tgts.cuda(), mask.cuda(), valid.clone().cuda(), seg_type.cuda(), merge)
+
+
 def test_ignore_rule_and_determinism():
     cfg = O.small_config()
     m, P = build(cfg, 1, "bf16")
