@@ -198,6 +198,33 @@ def test_small_seggpt_feature_ensemble_under_autograd_vs_oracle(dtype, n, merge)
     m.train()
     with pytest.raises(NotImplementedError, match="eval mode"):
         m(imgs.cuda(), tgts.cuda(), mask.cuda(), valid.clone().cuda(), seg_type.cuda(), merge)
+    # train mode WITHOUT the ensemble (merge_between_batch = -1) is an ordinary training step of the SegGPT module: DropPath factors
+    # (one per block here, shared by its two branches, so that the oracle can take them) + the type-token gradients
+    g = torch.Generator().manual_seed(5)
+    scales, over = [], []
+    for i, blk in enumerate(m.blocks):
+        if blk.drop_path_prob <= 0.0:
+            scales.append(None)
+            over.append((None, None))
+            continue
+        keep = 1.0 - blk.drop_path_prob
+        bc = 2 * n if i <= cfg.merge_idx else n
+        sc = torch.floor(keep + torch.rand(bc, generator=g)) / keep
+        scales.append(sc)
+        over.append((sc.cuda(), sc.cuda()))
+    m._drop_override = over
+    for p_ in m.parameters():
+        p_.grad = None
+    loss, _, _ = m(imgs.cuda(), tgts.cuda(), mask.cuda(), valid.clone().cuda(), seg_type.cuda(), -1)
+    loss.backward()
+    Pt = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    lt, _, _ = O.forward(Pt, cfg, imgs, tgts, mask.bool().expand(n, L), valid.clone(), seg_type, -1, drop_scales=scales)
+    lt.backward()
+    assert abs(loss.item() - lt.item()) < tol_l * abs(lt.item()), (loss.item(), lt.item())
+    for name in ("type_token_cls", "type_token_ins", "blocks.20.attn.qkv.weight", "patch_embed.proj.weight"):
+        go, gm = Pt[name].grad, dict(m.named_parameters())[name].grad
+        e = float((gm.cpu().reshape(go.shape) - go).abs().max()) / float(go.abs().max())
+        assert e < tol_g, (name, e)
 
 
 def test_ignore_rule_and_determinism():
