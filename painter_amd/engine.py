@@ -243,17 +243,19 @@ class HotPath:
                 ops.attn_fwd(qkv, rcat, Bc, L, c.heads, c.Hp, c.Wp, c.scale) + (None,)
             group = 0
             if merge > 0:
-                # Differentiable like the reference's Block.forward (models_seggpt.py:207-238) as long as no DropPath factor sits between the
-                # ensemble and the residual add (eval mode, or drop_path_rate 0): mean-over-the-group + broadcast is its own adjoint, the
-                # backward applies the same operator to the branch gradient.  The reference itself only runs it under @torch.no_grad
-                # (seggpt_engine.py:26); with DropPath draws (train mode) the scaled form is not built.
-                if need_grad and ds_a is not None:
-                    raise NotImplementedError("SegGPT feature ensemble under autograd needs eval mode or drop_path_rate = 0 "
-                                              "(the DropPath-scaled ensemble backward is not built; the reference runs the ensemble under "
-                                              "@torch.no_grad, seggpt_engine.py:26)")
+                # x1 = x0 + s_a * ens(proj(...)) (models_seggpt.py:207-238).  Differentiable like the reference's Block.forward: mean over
+                # the group + broadcast is its own adjoint, the backward applies the same operator to the (DropPath-scaled) branch
+                # gradient.  The reference itself only runs the ensemble under @torch.no_grad (seggpt_engine.py:26); with DropPath
+                # factors (train mode) the scaled form is composed from the same kernels: ens alone, the row-scale kernel, a plain add
+                # (= the ensemble kernel with groups of one).
                 a = ops.linear_fwd(ao, self.w(pre + "attn.proj.weight", P), P[pre + "attn.proj.bias"], EPI_BIAS_F32)
                 group = Bc // 2 if merge == 1 else Bc
-                x1 = ops.ensemble_resid(x, a, Bc, group, L, D)
+                if ds_a is None:
+                    x1 = ops.ensemble_resid(x, a, Bc, group, L, D)
+                else:
+                    e = ops.ensemble_resid(torch.zeros_like(x), a, Bc, group, L, D)
+                    x1 = ops.ensemble_resid(x, ops.scale_cast(torch.float32, e, ds_a, L), Bc, 1, L, D)
+                    del e
             else:
                 x1 = ops.linear_fwd(ao, self.w(pre + "attn.proj.weight", P), P[pre + "attn.proj.bias"], EPI_BIAS_RESID,
                                     resid=x, rowscale=ds_a, rows_per_sample=L)
@@ -446,10 +448,10 @@ class HotPath:
             G[pre + "norm2.weight"], G[pre + "norm2.bias"] = gb[0], gb[1]
             # ---- attention branch: x1 = x0 + s_a * proj(attn(LN1(x0)))
             if ens_group > 0:
-                # SegGPT feature ensemble (forward: x1 = x0 + ens(proj(...)), no DropPath factor): the branch gradient is ens applied to
-                # dx (fp32: the kernel's own type), re-rounded to the operand type.  Column sums are unchanged by a mean + broadcast over
-                # samples, so the proj bias gradient the LayerNorm backward already summed stands.
-                da = ops.ensemble_resid(torch.zeros_like(dx), dx, Bc, ens_group, L, D)
+                # SegGPT feature ensemble (forward: x1 = x0 + s_a * ens(proj(...))): the branch gradient is ens applied to s_a * dx (fp32: the
+                # kernel's own type), re-rounded to the operand type.  Column sums are unchanged by a mean + broadcast over samples, so
+                # the proj bias gradient the LayerNorm backward already summed (of s_a * dx) stands.
+                da = ops.ensemble_resid(torch.zeros_like(dx), dx if ds_a is None else ops.scale_cast(torch.float32, dx, ds_a, L), Bc, ens_group, L, D)
                 dyA = da if T == torch.float32 else ops.cast_bf16(da, out=dyA)
                 del da
             param_grads(pre + "attn.proj.weight", pre + "attn.proj.bias", dyA, ao, fl["proj"])

@@ -3,8 +3,8 @@
 `SegGPT` = the Painter network + two segmentation-type tokens (models_seggpt.py:285-286, :415-420), the cross-prompt
 feature ensemble inside each block (`Block.forward(x, merge)`, :220-232, schedule :426-429) and the loss without the
 ignore rule (:448-469).  Forward and backward run entirely in libpainter_hip.so.  The reference only ever runs the ensemble under
-@torch.no_grad (seggpt_engine.py:26); it is differentiable here too in eval mode / with drop_path_rate 0 (no DropPath factor between
-the ensemble and the residual add; engine.py), and refuses in train mode.
+@torch.no_grad (seggpt_engine.py:26); like the reference's Block.forward it is differentiable here too (engine.py), in eval and in
+train mode, and the two type tokens get their gradients.
 """
 from functools import partial
 
