@@ -37,19 +37,22 @@ enum {
 };
 
 /* Bumped whenever an entry point's argument list changes (2: `tables` in pa_attn_fwd / pa_attn_bwd; 3: `head_dim` in the attention and
- * rel-pos entry points; 4: `dxT_colsum` in pa_layernorm_bwd, `relpos_part` in pa_attn_bwd, `dx_colsum` in pa_linear_dgrad).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
-#define PA_ABI_VERSION 4
+ * rel-pos entry points; 4: `dxT_colsum` in pa_layernorm_bwd, `relpos_part` in pa_attn_bwd, `dx_colsum` in pa_linear_dgrad; 5: the bf16 GELU side output is gelu'(pre), pa_debug_set(9) and pa_attn4_trace are gone).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
+#define PA_ABI_VERSION 5
 int pa_abi_version(void);
 /* diagnostics only (tools/): which = 0 start-up stagger of alternate workgroup rows of the 256x256 GEMM in shader cycles,
  * 1 drop that kernel's epilogue stores (never set by the product path); 3 = TUNING, set by the engine: target number of workgroups
  * of the weight-gradient GEMM (0 = 256, the whole chip; 64 when the weight gradients run on a side stream); 4 = row-tile height of the un-split bf16
  * GEMMs: 0 by rule (224 rows where that fills the last round of workgroups better), 1 always 256, 2 224 wherever possible; 6 = K splits of the
  * rel-pos table-gradient GEMM; 7 = rel-pos table gradient inside the generation-3 dQ kernel: 0 default (on), 1 off, 2 on (tests);
- * 8 = generation-3 attention: workgroups with idle waves dispatched last: 0 default (on), 1 off, 2 on;
- * 9 = generation-4 (64-row waves, csrc/attn4.hip) dQ kernel: 0 default (off: experiment), 1 off, 2 on (its parity test). */
+ * 8 = generation-3 attention: workgroups with idle waves dispatched last: 0 default (on), 1 off, 2 on. */
 int pa_debug_set(int which, int value);
 
-/* ---- nn.Linear: y = x W^T + b.  models_painter.py:76 (qkv), :87 (proj), timm Mlp fc1/fc2 (:201,:230) ---- */
+/* ---- nn.Linear: y = x W^T + b.  models_painter.py:76 (qkv), :87 (proj), timm Mlp fc1/fc2 (:201,:230) ----
+ * PA_EPI_BIAS_GELU: out = gelu(pre), pre = x W^T + b rounded to T; out2 (optional, T [M,N] ld=ldo) receives what the backward needs of
+ * pre, to be handed to pa_linear_dgrad as `gelu_aux`: pre itself for PA_F32 (erf-GELU' is evaluated on it there, to fp32 accuracy), the
+ * DERIVATIVE gelu'(pre) = Phi(pre) + pre phi(pre) rounded to bf16 for PA_BF16 (ABI 5: the forward epilogue has both factors in
+ * registers, and the fc2 data gradient's epilogue becomes one load and one multiply instead of an erf evaluation). */
 int pa_linear_fwd(int dtype, int epilogue, const void* x /*T [M,K]*/, int64_t ldx, const void* w /*T [N,K]*/,
                   const float* bias /*[N]*/, void* out, void* out2, int64_t ldo, const float* resid /*f32 [M,N] ld=ldo*/,
                   const float* rowscale /*[M/rows_per_sample] or NULL*/, int rows_per_sample, int M, int N, int K,
@@ -57,13 +60,13 @@ int pa_linear_fwd(int dtype, int epilogue, const void* x /*T [M,K]*/, int64_t ld
 /* decoder_embed + pixel shuffle 'nhwpqc->nchpwq' (models_painter.py:423-428); output is NHWC [B, Hp*P, Wp*P, C] T */
 int pa_linear_pixshuf(int dtype, const void* x, int64_t ldx, const void* w /*T [P*P*C, K]*/, const float* bias,
                       void* out_nhwc, int batch, int Hp, int Wp, int P, int C, int K, hipStream_t stream);
-/* autograd of the above: dX = dY.W (optionally * gelu'(pre)), dW = dY^T.X (fp32), db = colsum(dY).
+/* autograd of the above: dX = dY.W (optionally * gelu'(pre), from the `out2` of pa_linear_fwd(PA_EPI_BIAS_GELU) of the same dtype), dW = dY^T.X (fp32), db = colsum(dY).
  * dx_colsum (optional, f32 [K], with workspace = pa_linear_dgrad_workspace_bytes(M, K)): the column sums of dX (fp32, in front of its rounding to T on the bf16 fast path) -- dX is the dY
  * of the layer in front (fc1 behind the GELU), so this is that layer's bias gradient, taken in the GEMM's epilogue instead of a second
  * pass over dX. */
 int64_t pa_linear_dgrad_workspace_bytes(int M, int K);
 int pa_linear_dgrad(int dtype, const void* dy /*T [M,N]*/, int64_t lddy, const void* w /*T [N,K]*/,
-                    const void* pre_for_dgelu /*T [M,K] ld=lddx or NULL*/, void* dx /*T [M,K]*/, int64_t lddx, float* dx_colsum,
+                    const void* gelu_aux /*T [M,K] ld=lddx or NULL*/, void* dx /*T [M,K]*/, int64_t lddx, float* dx_colsum,
                     void* workspace, int M, int N, int K, hipStream_t stream);
 int64_t pa_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K);
 int pa_linear_wgrad(int dtype, const void* dy /*T [M,N]*/, int64_t lddy, const void* x /*T [M,K]*/, int64_t ldx,
@@ -108,8 +111,6 @@ int pa_attn_set_generation(int generation);
 /* diagnostics: enable != 0 runs the generation-3 dQ kernel with s_memtime stamps (two workgroups, waves 0 / 1, 64 tiles, 8 slots);
  * host_out (may be NULL) receives the 2 x 2 x 64 x 8 stamps of the last traced launch */
 int pa_attn_trace(int enable, unsigned long long* host_out);
-/* diagnostics: the 64 x 8 s_memtime stamps of the generation-4 dQ kernel's stamped experiment variant (all zero in product builds) */
-int pa_attn4_trace(unsigned long long* host_out);
 int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse,
                 void* tables, int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t stream);
 

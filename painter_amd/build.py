@@ -73,6 +73,11 @@ def build(force=False, verbose=True):
     with cf.ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
         res = list(ex.map(lambda s: _compile(s, force), srcs))
     objs = [o for o, _ in res]
+    # prune objects / stamps whose source is gone (a retired kernel file would otherwise ride along in the shipped snapshot)
+    keep = {os.path.basename(o) for o in objs}
+    for f in os.listdir(OBJ):
+        if f.endswith(".o") and f not in keep or f.endswith(".o.stamp") and f[:-6] not in keep:
+            os.remove(os.path.join(OBJ, f))
     if force or any(c for _, c in res) or not os.path.exists(LIB):
         cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

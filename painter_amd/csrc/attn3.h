@@ -17,10 +17,3 @@ int attn3_bwd_prep(const bf16* out, int64_t ldo, const bf16* dout, int64_t lddo,
                    float scale, hipStream_t st);
 int64_t attn3_relpos_partials_bytes(int Bn, int L, int H, int Hp, int Wp);       // 0: not fused for this grid (or PA_ATTN3_FUSE_RELPOS=0)
 int attn3_relpos_reduce(const float* part, float* drcat, float* tmp, int Bn, int L, int H, int Hp, int Wp, hipStream_t st);
-// generation 4 (attn4.hip): 64-row waves for the backward; takes the whole 8-tile groups of every head, the rest stays on generation 3
-int attn4_groups(int L, int Hp, int Wp);           // 8-tile groups per head (0: not used for this grid / switched off)
-bool attn4_dkv_on();                                // is the 64-key dKV kernel built / switched on (PA_ATTN4_DKV)
-int attn4_bwd_dkv(const bf16* qkv, int64_t ldq, const bf16* dout, int64_t lddo, const void* tables, bf16* dqkv, int Bn, int L, int H, int Hp,
-                  int Wp, float scale, int xcd_map, hipStream_t st);
-int attn4_bwd_dq(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const void* tables,
-                 bf16* dqkv, float* part, int Bn, int L, int H, int Hp, int Wp, float scale, int xcd_map, hipStream_t st);

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
                                                           const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv,
                                                           bf16* __restrict__ dG, float* __restrict__ part, int L, int H, int Hp, int NRP,
                                                           float scale, int nblk, int xcd_map, int abl, int tile0, int pslot0) {
-    // tile0: first 32-query tile of every head this launch covers (generation 4 takes the whole 8-tile groups below it, attn4.hip);
+    // tile0: first 32-query tile of every head this launch covers (0 in the product; a launch may cover the tail of every head only);
     // pslot0: first partial slot of this launch in `part`
     // abl (diagnostics, PA_ATTN3_DQ_ABL; results are WRONG with any bit set): 1 no r-space loop after the key loop, 2 no dG stores,
     // 4 no dQ store, 16 no key loop, 32 no gather in the r-space loop, 64 no MFMA in the r-space loop
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dkv_kernel(const bf16* __restric
                                                            size_t lddo, const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv,
                                                            int L, int H, int Hp, float scale, int nblk, int xcd_map, int abl, int tile0) {
     // abl (diagnostics, PA_ATTN3_DKV_ABL; results WRONG when set): 16 no query loop
-    // tile0: first 32-key tile of every head this launch covers (generation 4 takes the whole 8-tile groups below it)
+    // tile0: first 32-key tile of every head this launch covers (0 in the product)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5, ql = lane & 31;
     int blk, bh;
@@ -856,12 +856,9 @@ static int a3_fuse_on() {
     static const int v = [] { const char* e = getenv("PA_ATTN3_FUSE_RELPOS"); return e ? atoi(e) : 1; }();
     return g_attn3_fuse == 1 ? 0 : (g_attn3_fuse == 2 ? 1 : v);
 }
-// workgroups of the dQ launches = partial slots: generation 4 takes `ngrp` whole 8-tile groups per head, generation 3 the tiles behind them
-static int a3_rem_blocks(int L, int ngrp) { return (L / 32 - 8 * ngrp + a3::NW - 1) / a3::NW; }
-static int64_t a3_num_partials(int Bn, int L, int H, int Hp, int Wp) {
-    const int ngrp = attn4_groups(L, Hp, Wp);
-    return (int64_t)(ngrp + a3_rem_blocks(L, ngrp)) * Bn * H;
-}
+// workgroups of the dQ launch = partial slots
+static int a3_blocks(int L) { return (L / 32 + a3::NW - 1) / a3::NW; }
+static int64_t a3_num_partials(int Bn, int L, int H, int, int) { return (int64_t)a3_blocks(L) * Bn * H; }
 int64_t attn3_relpos_partials_bytes(int Bn, int L, int H, int Hp, int Wp) {
     if (!a3_fuse_on() || !attn3_ok(L, Hp, Wp)) return 0;
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
@@ -893,15 +890,13 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
         PA_LAUNCH(prep_kernel, dim3((total + 255) / 256), dim3(256), 0, st, lse, delta, tb, L, Hp, 1.f / scale, total);
         if ((e = (int)hipGetLastError())) return e;
     }
-    // generation 4 (attn4.hip, 64-row waves) takes the whole 8-tile groups of every head when the rel-pos gradient is fused; the tiles
-    // behind them (the 49th of 49 at the ViT-L grid) and every other case run here
-    const int ngrp = part != nullptr ? attn4_groups(L, Hp, Wp) : 0;
-    const int tile0 = 8 * ngrp;
-    const int nblk = a3_rem_blocks(L, ngrp);
+    // (the 64-row-wave generation 4 of round 4, which took whole 8-tile groups of every head in front of these launches, measured 40 %
+    // slower and lives on the branch exp/attn4-generation-4: DESIGN.md section 4.2d)
+    const int tile0 = 0;
+    const int nblk = a3_blocks(L);
     // PA_ATTN3_DQ_WAVES / PA_ATTN3_DKV_WAVES: waves per SIMD the register allocation aims at (2 or 3)
     static const int dq_w = [] { const char* v = getenv("PA_ATTN3_DQ_WAVES"); return v ? atoi(v) : 2; }();
     static const int dkv_w = [] { const char* v = getenv("PA_ATTN3_DKV_WAVES"); return v ? atoi(v) : 2; }();
-    if (ngrp > 0 && (e = attn4_bwd_dq(qkv, ldq, rcatT, dout, lddo, lse, tables, dqkv, part, Bn, L, H, Hp, Wp, scale, a3_xcd_map_on(), st))) return e;
     if (nblk > 0) {
         static const size_t pad = [] { const char* v = getenv("PA_ATTN3_LDS_PAD"); return v ? (size_t)atoi(v) : (size_t)0; }();   // diagnostics: fewer workgroups per CU
         size_t smem = 2 * (size_t)STAGE_QK + (size_t)NW * Hp * 64 + PH * EIMG + (size_t)ATT_HD * (NRP * 2 + 16) + pad;
@@ -916,12 +911,10 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
         if ((e = set_smem(reinterpret_cast<const void*>(kern), fuse ? donef : (g_attn_trace ? donet : (dq_w == 3 ? done3 : done2))))) return e;
         const char* ablv = getenv("PA_ATTN3_DQ_ABL");           // diagnostics, read per launch
         PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcatT, dout, (size_t)lddo, lse, tb, dqkv, dG, part, L, H,
-                  Hp, NRP, scale, nblk, a3_xcd_map_on(), ablv ? atoi(ablv) : 0, tile0, ngrp * Bn * H);
+                  Hp, NRP, scale, nblk, a3_xcd_map_on(), ablv ? atoi(ablv) : 0, tile0, 0);
         if ((e = (int)hipGetLastError())) return e;
     }
-    const int ngrp_kv = attn4_dkv_on() ? ngrp : 0;
-    if (ngrp_kv > 0 && (e = attn4_bwd_dkv(qkv, ldq, dout, lddo, tables, dqkv, Bn, L, H, Hp, Wp, scale, a3_xcd_map_on(), st))) return e;
-    const int tile0_kv = 8 * ngrp_kv, nblk_kv = a3_rem_blocks(L, ngrp_kv);
+    const int tile0_kv = 0, nblk_kv = a3_blocks(L);
     if (nblk_kv > 0) {
         size_t smem = 2 * (size_t)DKV_STAGE;
         if (smem < (size_t)NW * 2 * IMG) smem = (size_t)NW * 2 * IMG;

@@ -121,8 +121,6 @@ inline int g_relpos_splits = 0;
 inline int g_attn3_fuse = 0;
 // pa_debug_set(8, v): 0 = default (light attention workgroups dispatched last unless PA_ATTN_LIGHT_LAST=0), 1 = off, 2 = on
 inline int g_attn_light_last = 0;
-// pa_debug_set(9, v): 0 = default (generation-4 64-row attention backward OFF unless PA_ATTN4=1: experiment, attn4.hip), 1 = off, 2 = on
-inline int g_attn4 = 0;
 
 // exact (erf) GELU and its derivative -- nn.GELU default (Painter/models_painter.py:253)
 DEVI float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -151,17 +149,11 @@ DEVI float gelu_fast(float x) {
     gelu_parts(x, c, e);
     return x * c;
 }
-DEVI float gelu_grad_fast(float x) {
-    float c, e;
-    gelu_parts(x, c, e);
-    return fmaf(x * 0.39894228040143268f, e, c);
-}
-
 // Two elements at once for the gemm256 epilogues, where the GELU is 33 us of the 154 us fc1 launch with the matrix pipe idle
 // (tools/fc1_epilogue.py): the same A-S polynomial on float2 values -- hipcc emits v_pk_mul / v_pk_fma / v_pk_add_f32 for these, half
 // the issue slots of the scalar form -- with the constants folded (0.5 into the coefficients, 1/sqrt2 into the rcp argument) and the
 // sign handled by copysign instead of compare + select.  Packed fp32 arithmetic is bit-identical to scalar, alone and beside MFMA
-// kernels (tools/ubench); only rcp and exp2 stay per element.  Results equal gelu_fast / gelu_grad_fast up to the
+// kernels (tools/ubench); only rcp and exp2 stay per element.  Results equal gelu_fast (and the gelu' built from gelu_parts) up to the
 // association of the folded constants (1-2 ulp of fp32, far below the bf16 rounding that follows).
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 DEVI void gelu_parts2(f32x2_t x, f32x2_t& cdf, f32x2_t& e) {
@@ -184,13 +176,14 @@ DEVI f32x2_t gelu_fast2(float x0, float x1) {
     gelu_parts2(x, c, e);
     return x * c;
 }
-DEVI f32x2_t gelu_grad_fast2(float x0, float x1) {
+// gelu(x) and gelu'(x) from one evaluation of the shared parts: the fc1 forward epilogue stores both (act and, for the backward, gelu')
+DEVI void gelu_both2(float x0, float x1, f32x2_t& y, f32x2_t& dy) {
     const f32x2_t x = {x0, x1};
     f32x2_t c, e;
     gelu_parts2(x, c, e);
-    return __builtin_elementwise_fma(x * (f32x2_t){0.39894228040143268f, 0.39894228040143268f}, e, c);
+    y = x * c;
+    dy = __builtin_elementwise_fma(x * (f32x2_t){0.39894228040143268f, 0.39894228040143268f}, e, c);
 }
-
 // 4x4 transpose of a register block: in[i] = 4 consecutive elements (along r) of contraction row i;
 // out[j] = the 4 contraction values of element r+j.
 DEVI void transpose4x4(const uint4 (&in)[4], uint4 (&out)[4]) {   // float

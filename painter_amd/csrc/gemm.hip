@@ -15,14 +15,25 @@ template <typename OutT> struct EpiBias {   // out[i][j] = acc + bias[j]
         });
     }
 };
-template <typename T> struct EpiBiasGelu {   // pre = acc + bias (rounded to T); act = gelu(pre)
-    T* pre; T* act; size_t ld; const float* bias; int M, N;
+// pre = acc + bias (rounded to T); act = gelu(pre).  What the backward needs of `pre` is saved in `aux`: the pre-activation itself in the
+// exact-fp32 build (the fc2 data gradient evaluates erf-GELU' on it to 1e-7), gelu'(pre) rounded to bf16 in the bf16 build -- the forward
+// epilogue has Phi(pre) and exp(-pre^2 / 2) in registers anyway, and the fc2 data-gradient epilogue becomes one load and one multiply.
+template <typename T> struct EpiBiasGelu {
+    T* aux; T* act; size_t ld; const float* bias; int M, N;
     DEVI void operator()(const f32x16 (&acc)[2][2], int ib, int jb, int lane, int) const {
         foreach_acc(acc, ib, jb, lane, [&](int i, int j, float v) {
             if (i < M && j < N) {
                 const T p = from_f<T>(v + bias[j]);
-                if (pre) pre[(size_t)i * ld + j] = p;
-                act[(size_t)i * ld + j] = from_f<T>(gelu_f(to_f(p)));
+                if constexpr (std::is_same<T, bf16>::value) {
+                    float c, e;
+                    const float x = to_f(p);
+                    gelu_parts(x, c, e);
+                    if (aux) aux[(size_t)i * ld + j] = from_f<T>(fmaf(x * 0.39894228040143268f, e, c));
+                    act[(size_t)i * ld + j] = from_f<T>(x * c);
+                } else {
+                    if (aux) aux[(size_t)i * ld + j] = p;
+                    act[(size_t)i * ld + j] = from_f<T>(gelu_f(to_f(p)));
+                }
             }
         });
     }
@@ -38,11 +49,14 @@ struct EpiBiasResid {   // out = resid + rowscale[i / rps] * (acc + bias)   (res
         });
     }
 };
-template <typename T> struct EpiDGelu {   // out = acc * gelu'(pre)
-    T* out; const T* pre; size_t ld; int M, N;
+template <typename T> struct EpiDGelu {   // out = acc * gelu'(pre); aux = what EpiBiasGelu<T> saved (fp32: pre, bf16: gelu'(pre))
+    T* out; const T* aux; size_t ld; int M, N;
     DEVI void operator()(const f32x16 (&acc)[2][2], int ib, int jb, int lane, int) const {
         foreach_acc(acc, ib, jb, lane, [&](int i, int j, float v) {
-            if (i < M && j < N) out[(size_t)i * ld + j] = from_f<T>(v * gelu_grad_f(to_f(pre[(size_t)i * ld + j])));
+            if (i < M && j < N) {
+                const float a = to_f(aux[(size_t)i * ld + j]);
+                out[(size_t)i * ld + j] = from_f<T>(v * (std::is_same<T, bf16>::value ? a : gelu_grad_f(a)));
+            }
         });
     }
 };
@@ -106,8 +120,8 @@ template <typename OutT> struct Epi4Bias {
         store8(out + (size_t)i * ldo + j, add4(a, c.a), add4(b, c.b));
     }
 };
-struct Epi4BiasGelu {
-    bf16* pre; bf16* act; size_t ld; const float* bias; int M, N;
+struct Epi4BiasGelu {       // aux (optional): gelu'(pre) as bf16, where rounds 1-4 stored pre itself (see EpiBiasGelu)
+    bf16* aux; bf16* act; size_t ld; const float* bias; int M, N;
     typedef EpiCol8 Col;
     typedef EpiNone Row;
     DEVI Col col(int j) const { return load_col8(bias, j, N); }
@@ -116,11 +130,21 @@ struct Epi4BiasGelu {
         if (i >= M || j >= N) return;
         a = add4(a, c.a);
         b = add4(b, c.b);
+        // GELU and GELU' are taken of the bf16-ROUNDED pre-activation, as the reference's autocast path does (its fc1 output is a bf16 tensor)
         const uint4 pk = make_uint4(pack_bf16x2(a.x, a.y), pack_bf16x2(a.z, a.w), pack_bf16x2(b.x, b.y), pack_bf16x2(b.z, b.w));
-        if (pre) *reinterpret_cast<uint4*>(pre + (size_t)i * ld + j) = pk;
-        const f32x2_t g0 = gelu_fast2(bf16_lo(pk.x), bf16_hi(pk.x)), g1 = gelu_fast2(bf16_lo(pk.y), bf16_hi(pk.y)),
-                      g2 = gelu_fast2(bf16_lo(pk.z), bf16_hi(pk.z)), g3 = gelu_fast2(bf16_lo(pk.w), bf16_hi(pk.w));
-        store8(act + (size_t)i * ld + j, make_float4(g0[0], g0[1], g1[0], g1[1]), make_float4(g2[0], g2[1], g3[0], g3[1]));
+        if (aux) {
+            f32x2_t g0, g1, g2, g3, d0, d1, d2, d3;
+            gelu_both2(bf16_lo(pk.x), bf16_hi(pk.x), g0, d0);
+            gelu_both2(bf16_lo(pk.y), bf16_hi(pk.y), g1, d1);
+            gelu_both2(bf16_lo(pk.z), bf16_hi(pk.z), g2, d2);
+            gelu_both2(bf16_lo(pk.w), bf16_hi(pk.w), g3, d3);
+            store8(aux + (size_t)i * ld + j, make_float4(d0[0], d0[1], d1[0], d1[1]), make_float4(d2[0], d2[1], d3[0], d3[1]));
+            store8(act + (size_t)i * ld + j, make_float4(g0[0], g0[1], g1[0], g1[1]), make_float4(g2[0], g2[1], g3[0], g3[1]));
+        } else {
+            const f32x2_t g0 = gelu_fast2(bf16_lo(pk.x), bf16_hi(pk.x)), g1 = gelu_fast2(bf16_lo(pk.y), bf16_hi(pk.y)),
+                          g2 = gelu_fast2(bf16_lo(pk.z), bf16_hi(pk.z)), g3 = gelu_fast2(bf16_lo(pk.w), bf16_hi(pk.w));
+            store8(act + (size_t)i * ld + j, make_float4(g0[0], g0[1], g1[0], g1[1]), make_float4(g2[0], g2[1], g3[0], g3[1]));
+        }
     }
 };
 struct Epi4BiasResid {
@@ -146,24 +170,21 @@ struct Epi4BiasResid {
                make_float4(r.rb.x + s * b.x, r.rb.y + s * b.y, r.rb.z + s * b.z, r.rb.w + s * b.w));
     }
 };
-struct Epi4DGelu {
-    bf16* out; const bf16* pre; size_t ld; int M, N;
+struct Epi4DGelu {          // out = acc * aux, aux = the bf16 gelu'(pre) the fc1 forward epilogue saved (Epi4BiasGelu)
+    bf16* out; const bf16* aux; size_t ld; int M, N;
     typedef EpiNone Col;
     struct Row { uint4 p; };
     DEVI Col col(int) const { return Col{}; }
     DEVI Row row(int i, int j) const {
         Row r{make_uint4(0, 0, 0, 0)};
-        if (i < M && j < N) r.p = *reinterpret_cast<const uint4*>(pre + (size_t)i * ld + j);
+        if (i < M && j < N) r.p = *reinterpret_cast<const uint4*>(aux + (size_t)i * ld + j);
         return r;
     }
     DEVI void store(int i, int j, float4 a, float4 b, const Col&, const Row& r, int) const {
         if (i >= M || j >= N) return;
         const uint4 w = r.p;
-        const float4 pa = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
-        const float4 pb = make_float4(bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w));
-        const f32x2_t g0 = gelu_grad_fast2(pa.x, pa.y), g1 = gelu_grad_fast2(pa.z, pa.w), g2 = gelu_grad_fast2(pb.x, pb.y), g3 = gelu_grad_fast2(pb.z, pb.w);
-        store8(out + (size_t)i * ld + j, make_float4(a.x * g0[0], a.y * g0[1], a.z * g1[0], a.w * g1[1]),
-               make_float4(b.x * g2[0], b.y * g2[1], b.z * g3[0], b.w * g3[1]));
+        store8(out + (size_t)i * ld + j, make_float4(a.x * bf16_lo(w.x), a.y * bf16_hi(w.x), a.z * bf16_lo(w.y), a.w * bf16_hi(w.y)),
+               make_float4(b.x * bf16_lo(w.z), b.y * bf16_hi(w.z), b.z * bf16_lo(w.w), b.w * bf16_hi(w.w)));
     }
 };
 // the same with the column sums of dX (the fp32 values in front of its bf16 rounding; gemm256.h, epi_colsum): part f32 [2 * row tiles][N]
@@ -172,14 +193,12 @@ struct Epi4DGeluCS : Epi4DGelu {
     DEVI void store_cs(int i, int j, float4 a, float4 b, const Col&, const Row& r, int, float (&cs)[8]) const {
         if (i >= M || j >= N) return;
         const uint4 w = r.p;
-        const float4 pa = make_float4(bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y));
-        const float4 pb = make_float4(bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w));
-        const f32x2_t g0 = gelu_grad_fast2(pa.x, pa.y), g1 = gelu_grad_fast2(pa.z, pa.w), g2 = gelu_grad_fast2(pb.x, pb.y), g3 = gelu_grad_fast2(pb.z, pb.w);
-        const uint4 pk = make_uint4(pack_bf16x2(a.x * g0[0], a.y * g0[1]), pack_bf16x2(a.z * g1[0], a.w * g1[1]),
-                                    pack_bf16x2(b.x * g2[0], b.y * g2[1]), pack_bf16x2(b.z * g3[0], b.w * g3[1]));
+        const float g[8] = {bf16_lo(w.x), bf16_hi(w.x), bf16_lo(w.y), bf16_hi(w.y), bf16_lo(w.z), bf16_hi(w.z), bf16_lo(w.w), bf16_hi(w.w)};
+        const uint4 pk = make_uint4(pack_bf16x2(a.x * g[0], a.y * g[1]), pack_bf16x2(a.z * g[2], a.w * g[3]),
+                                    pack_bf16x2(b.x * g[4], b.y * g[5]), pack_bf16x2(b.z * g[6], b.w * g[7]));
         *reinterpret_cast<uint4*>(out + (size_t)i * ld + j) = pk;
-        cs[0] = fmaf(a.x, g0[0], cs[0]); cs[1] = fmaf(a.y, g0[1], cs[1]); cs[2] = fmaf(a.z, g1[0], cs[2]); cs[3] = fmaf(a.w, g1[1], cs[3]);      // the fp32 values in front of the rounding
-        cs[4] = fmaf(b.x, g2[0], cs[4]); cs[5] = fmaf(b.y, g2[1], cs[5]); cs[6] = fmaf(b.z, g3[0], cs[6]); cs[7] = fmaf(b.w, g3[1], cs[7]);
+        cs[0] = fmaf(a.x, g[0], cs[0]); cs[1] = fmaf(a.y, g[1], cs[1]); cs[2] = fmaf(a.z, g[2], cs[2]); cs[3] = fmaf(a.w, g[3], cs[3]);      // the fp32 values in front of the rounding
+        cs[4] = fmaf(b.x, g[4], cs[4]); cs[5] = fmaf(b.y, g[5], cs[5]); cs[6] = fmaf(b.z, g[6], cs[6]); cs[7] = fmaf(b.w, g[7], cs[7]);
     }
     DEVI void colsum_out(int prow, int j, const float (&cs)[8]) const {
         if (j >= N) return;
@@ -408,27 +427,29 @@ extern "C" int pa_linear_pixshuf(int dtype, const void* x, int64_t ldx, const vo
 
 // ------------------------------------------------------------------------------- linear backward
 // dX[M,K] = dY[M,N] . W[N,K]      (contraction over N; W is contraction-major -> OpT)
-// dx_colsum (optional, needs `pre`): f32 [K] = column sums of dX as stored -- partial rows from the GEMM's epilogue on the bf16 fast
-// path (workspace), a separate pa_colsum pass otherwise
+// dx_colsum (optional): f32 [K] = column sums of dX as stored -- partial rows from the GEMM's epilogue on the bf16 fast path when the
+// GELU side input is given (workspace), a separate pa_colsum pass over dX otherwise
 extern "C" int64_t pa_linear_dgrad_workspace_bytes(int M, int K) {
     const int64_t fast = (int64_t)2 * ((M + g256::BM_SHORT - 1) / g256::BM_SHORT) * K * sizeof(float);
     const int64_t slow = pa_colsum_workspace_bytes(M, K);
     return fast > slow ? fast : slow;
 }
 template <typename T>
-static int linear_dgrad_t(const T* dy, int64_t lddy, const T* w, const T* pre, T* dx, int64_t lddx, float* dx_colsum, float* ws, int M,
+static int linear_dgrad_t(const T* dy, int64_t lddy, const T* w, const T* pre /* = gelu_aux: EpiBiasGelu */, T* dx, int64_t lddx, float* dx_colsum, float* ws, int M,
                           int N, int K, hipStream_t st) {
     if constexpr (std::is_same<T, bf16>::value) {
         if (g256::ok(M, K, N, false, true, lddy, K)) {
             if (pre && dx_colsum) {
                 Epi4DGeluCS ep;
-                ep.out = dx; ep.pre = pre; ep.ld = (size_t)lddx; ep.M = M; ep.N = K; ep.part = ws;
+                ep.out = dx; ep.aux = pre; ep.ld = (size_t)lddx; ep.M = M; ep.N = K; ep.part = ws;
                 int e = g256::launch<false, true>(dy, lddy, w, K, ep, M, K, N, 1, st);
                 if (e) return e;
                 return pa_slab_reduce(ws, dx_colsum, K, 2 * g256::row_tiles_used(M, K, 1), K, 0, st);
             }
             if (pre) return g256::launch<false, true>(dy, lddy, w, K, Epi4DGelu{dx, pre, (size_t)lddx, M, K}, M, K, N, 1, st);
-            return g256::launch<false, true>(dy, lddy, w, K, Epi4Bias<bf16>{dx, (size_t)lddx, nullptr, M, K}, M, K, N, 1, st);
+            int e = g256::launch<false, true>(dy, lddy, w, K, Epi4Bias<bf16>{dx, (size_t)lddx, nullptr, M, K}, M, K, N, 1, st);
+            if (e || dx_colsum == nullptr) return e;
+            return pa_colsum(PA_BF16, dx, lddx, M, K, dx_colsum, ws, st);      // no GELU side input: a pass over the stored dX (the epilogue sums only exist beside it)
         }
     }
     OpN<T> A{dy, (size_t)lddy, M, 0};
@@ -439,12 +460,12 @@ static int linear_dgrad_t(const T* dy, int64_t lddy, const T* w, const T* pre, T
     if (e || dx_colsum == nullptr) return e;
     return pa_colsum(std::is_same<T, bf16>::value ? PA_BF16 : PA_F32, dx, lddx, M, K, dx_colsum, ws, st);
 }
-extern "C" int pa_linear_dgrad(int dtype, const void* dy, int64_t lddy, const void* w, const void* pre_for_dgelu,
+extern "C" int pa_linear_dgrad(int dtype, const void* dy, int64_t lddy, const void* w, const void* gelu_aux,
                                void* dx, int64_t lddx, float* dx_colsum, void* workspace, int M, int N, int K, hipStream_t st) {
     if (N % 8 || K % 4) return (int)hipErrorInvalidValue;
     if (dx_colsum != nullptr && (workspace == nullptr || K % 8 || lddx % 8)) return (int)hipErrorInvalidValue;
-    if (dtype == PA_BF16) return linear_dgrad_t<bf16>((const bf16*)dy, lddy, (const bf16*)w, (const bf16*)pre_for_dgelu, (bf16*)dx, lddx, dx_colsum, (float*)workspace, M, N, K, st);
-    return linear_dgrad_t<float>((const float*)dy, lddy, (const float*)w, (const float*)pre_for_dgelu, (float*)dx, lddx, dx_colsum, (float*)workspace, M, N, K, st);
+    if (dtype == PA_BF16) return linear_dgrad_t<bf16>((const bf16*)dy, lddy, (const bf16*)w, (const bf16*)gelu_aux, (bf16*)dx, lddx, dx_colsum, (float*)workspace, M, N, K, st);
+    return linear_dgrad_t<float>((const float*)dy, lddy, (const float*)w, (const float*)gelu_aux, (float*)dx, lddx, dx_colsum, (float*)workspace, M, N, K, st);
 }
 
 // dW[N,K] = dY[M,N]^T . X[M,K]    (contraction over M; both operands contraction-major), split-K + reduce
@@ -512,11 +533,10 @@ extern "C" int pa_linear_wgrad(int dtype, const void* dy, int64_t lddy, const vo
 
 extern "C" int pa_abi_version(void) { return PA_ABI_VERSION; }
 extern "C" int pa_debug_set(int which, int value) {
-    if (which < 0 || which > 9) return (int)hipErrorInvalidValue;
+    if (which < 0 || which > 8) return (int)hipErrorInvalidValue;
     if (which < 8) g256::g_dbg[which] = value;
     if (which == 6) g_relpos_splits = value;
     if (which == 7) g_attn3_fuse = value;
     if (which == 8) g_attn_light_last = value;
-    if (which == 9) g_attn4 = value;
     return 0;
 }

@@ -7,7 +7,7 @@ Backward is written by hand -- nothing is delegated to to
 
 Data layout in HBM (per rank):
   residual stream x        fp32 [B'*L, D]           B' = 2B for blocks 0..merge_idx, B afterwards
-  GEMM operands / acts     T    (bf16 or fp32)      ln out [R,D], qkv [R,3D], attn out [R,D], fc1 pre/act [R,4D]
+  GEMM operands / acts     T    (bf16 or fp32)      ln out [R,D], qkv [R,3D], attn out [R,D], fc1 act + gelu aux [R,4D]
   tap concat               T    [B*L, 4D]           LayerNorm of the 4 taps written straight into column slices
   decoder image            T    NHWC [B, H, W, 64]  pixel shuffle fused into decoder_embed's epilogue
   pred / loss              fp32 NCHW [B,3,H,W], [2]
@@ -260,11 +260,11 @@ class HotPath:
                 x1 = ops.linear_fwd(ao, self.w(pre + "attn.proj.weight", P), P[pre + "attn.proj.bias"], EPI_BIAS_RESID,
                                     resid=x, rowscale=ds_a, rows_per_sample=L)
             ln2, mean2, rstd2 = ops.layernorm_fwd(x1, P[pre + "norm2.weight"], P[pre + "norm2.bias"], c.ln_eps, T)
-            act, hpre = ops.linear_gelu(ln2, self.w(pre + "mlp.fc1.weight", P), P[pre + "mlp.fc1.bias"], need_pre=need_grad)
+            act, gaux = ops.linear_gelu(ln2, self.w(pre + "mlp.fc1.weight", P), P[pre + "mlp.fc1.bias"], need_aux=need_grad)
             x2 = ops.linear_fwd(act, self.w(pre + "mlp.fc2.weight", P), P[pre + "mlp.fc2.bias"], EPI_BIAS_RESID,
                                 resid=x1, rowscale=ds_m, rows_per_sample=L)
             if need_grad:
-                S.blocks.append((x, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc, atab, group))
+                S.blocks.append((x, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, gaux, act, Bc, atab, group))
             x = x2
             if i == c.merge_idx:
                 Bc = B
@@ -400,7 +400,7 @@ class HotPath:
         rc_shape = tuple(S.blocks[-1][5].shape)            # Rcat [NRP, head_dim]: the same for every block
         for i in reversed(range(c.depth)):
             pre = "blocks.%d." % i
-            x0, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, hpre, act, Bc, atab, ens_group = S.blocks[i]
+            x0, mean1, rstd1, ln1, qkv, rcat, ao, lse, x1, mean2, rstd2, ln2, gaux, act, Bc, atab, ens_group = S.blocks[i]
             S.blocks[i] = None
             R = Bc * L
             ds_a, ds_m = (None, None) if S.drop is None else S.drop[i]
@@ -429,7 +429,7 @@ class HotPath:
             param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dyT, act, fl["fc2"])
             tr("%d.dyT" % i, dyT)
             # (the GEMM's epilogue also sums the columns of the dpre it stores: fc1's bias gradient, no separate pass over [R, 4D])
-            dpre = ops.linear_dgrad(dyT, self.w(pre + "mlp.fc2.weight", P), pre=hpre, colsum_out=fl["fc1"])
+            dpre = ops.linear_dgrad(dyT, self.w(pre + "mlp.fc2.weight", P), gelu_aux=gaux, colsum_out=fl["fc1"])
             G[pre + "mlp.fc1.bias"] = fl["fc1"]
             tr("%d.dpre" % i, dpre)
             param_grads(pre + "mlp.fc1.weight", pre + "mlp.fc1.bias", dpre, ln2, fl["fc1"])
@@ -484,7 +484,7 @@ class HotPath:
             gb = on_side(fin, fin.buffer)
             G[pre + "norm1.weight"], G[pre + "norm1.bias"] = gb[0], gb[1]
             tr("%d.dx_ln1" % i, dx)
-            del x0, ln1, qkv, ao, x1, ln2, hpre, act, atab
+            del x0, ln1, qkv, ao, x1, ln2, gaux, act, atab
             ready([n for n in G if n.startswith(pre)], flat=flat)
         G["norm.weight"], G["norm.bias"] = dnorm[0], dnorm[1]
         # ---- token assembly + patch embed

@@ -58,13 +58,15 @@ def linear_fwd(x, w, bias, epilogue=EPI_BIAS, out=None, out2=None, resid=None, r
     return out
 
 
-def linear_gelu(x, w, bias, need_pre=True):
+def linear_gelu(x, w, bias, need_aux=True):
+    """-> (act = gelu(x W^T + b), aux): aux is what linear_dgrad(gelu_aux=...) needs of the pre-activation -- the pre-activation itself in the
+    exact-fp32 build, gelu'(pre) rounded to bf16 in the bf16 build (include/painter_hip.h, PA_EPI_BIAS_GELU)."""
     M = x.shape[0]
     N = w.shape[0]
     act = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    pre = torch.empty((M, N), dtype=x.dtype, device=x.device) if need_pre else None
-    linear_fwd(x, w, bias, EPI_BIAS_GELU, out=act, out2=pre)
-    return act, pre
+    aux = torch.empty((M, N), dtype=x.dtype, device=x.device) if need_aux else None
+    linear_fwd(x, w, bias, EPI_BIAS_GELU, out=act, out2=aux)
+    return act, aux
 
 
 def linear_pixshuf(x, w, bias, batch, Hp, Wp, P, C):
@@ -75,8 +77,8 @@ def linear_pixshuf(x, w, bias, batch, Hp, Wp, P, C):
     return out
 
 
-def linear_dgrad(dy, w, pre=None, out=None, colsum_out=None):
-    """dX[M,K] = dY[M,N] . W[N,K]  (* gelu'(pre) when pre is given).
+def linear_dgrad(dy, w, gelu_aux=None, out=None, colsum_out=None):
+    """dX[M,K] = dY[M,N] . W[N,K]  (* gelu'(pre) when gelu_aux, the second result of linear_gelu() in the same dtype, is given).
     colsum_out (f32 [K], optional): receives the column sums of dX as stored -- the bias gradient of the layer whose dY dX is -- from the
     GEMM's epilogue (bf16 fast path) instead of a separate pass."""
     M, N = dy.shape
@@ -85,13 +87,13 @@ def linear_dgrad(dy, w, pre=None, out=None, colsum_out=None):
     _req(dy); _req(w, T)
     if out is None:
         out = torch.empty((M, K), dtype=T, device=dy.device)
-    if pre is not None:
-        assert pre.stride(0) == out.stride(0)
+    if gelu_aux is not None:
+        assert gelu_aux.stride(0) == out.stride(0) and gelu_aux.dtype == T
     ws = None
     if colsum_out is not None:
         assert colsum_out.shape == (K,) and colsum_out.dtype == torch.float32 and colsum_out.is_contiguous()
         ws = workspace(lib.pa_linear_dgrad_workspace_bytes(M, K), dy.device, slot=2)
-    check(lib.pa_linear_dgrad(code(T), p(dy), dy.stride(0), p(w), p(pre), p(out), out.stride(0), p(colsum_out), p(ws), M, N, K, stream()),
+    check(lib.pa_linear_dgrad(code(T), p(dy), dy.stride(0), p(w), p(gelu_aux), p(out), out.stride(0), p(colsum_out), p(ws), M, N, K, stream()),
           "pa_linear_dgrad")
     return out
 

@@ -28,6 +28,30 @@ def gen(shape, seed, scale=1.0, dtype=torch.float32):
 TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
 
 
+def gelu_grad_ref(pre):
+    """d gelu / d pre (erf GELU, nn.GELU's default: models_painter.py:253) in float64 through torch autograd."""
+    pg = pre.double().clone().requires_grad_(True)
+    torch.nn.functional.gelu(pg).sum().backward()
+    return pg.grad
+
+
+def gelu_aux_of(pre):
+    """What ops.linear_gelu hands to ops.linear_dgrad(gelu_aux=...) for a pre-activation tensor of this dtype: the pre-activation itself
+    (fp32 build), gelu'(pre) rounded to bf16 (bf16 build; include/painter_hip.h, PA_EPI_BIAS_GELU)."""
+    return pre if pre.dtype == torch.float32 else gelu_grad_ref(pre).to(pre.dtype)
+
+
+def check_gelu_pair(x, w, b, act, aux, tol):
+    """act / aux of ops.linear_gelu against the pre-activation the same kernel rounds (the bias epilogue on the same operands: the same
+    accumulation order, hence the same bits in front of the GELU)."""
+    pre = ops.linear_fwd(x, w, b, EPI_BIAS)
+    assert relerr(act.float(), torch.nn.functional.gelu(pre.double())) < tol
+    if pre.dtype == torch.float32:
+        assert torch.equal(aux, pre)
+    else:
+        assert relerr(aux.float(), gelu_grad_ref(pre)) < tol
+
+
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("M,N,K", [(200, 192, 128), (64, 64, 72), (37 * 8, 384, 72 * 8), (12544, 1024, 1024)])
 def test_linear_fwd_epilogues(T, M, N, K):
@@ -40,9 +64,8 @@ def test_linear_fwd_epilogues(T, M, N, K):
     assert relerr(y.float(), ref) < TOL[T]
     y32 = ops.linear_fwd(x, w, b, EPI_BIAS_F32)
     assert relerr(y32, ref) < (2e-5 if T == torch.float32 else 1e-2)
-    act, pre = ops.linear_gelu(x, w, b)
-    assert relerr(pre.float(), ref) < TOL[T]
-    assert relerr(act.float(), torch.nn.functional.gelu(pre.float())) < TOL[T]
+    act, aux = ops.linear_gelu(x, w, b)
+    check_gelu_pair(x, w, b, act, aux, TOL[T])
     resid = gen((M, N), 4)
     rps = 8
     rowscale = gen(((M + rps - 1) // rps,), 5).abs() + 0.5
@@ -61,10 +84,8 @@ def test_linear_backward(T, M, N, K):
     dx_ref = dy.float() @ w.float()
     dx = ops.linear_dgrad(dy, w)
     assert relerr(dx.float(), dx_ref) < TOL[T]
-    xg = pre.float().clone().requires_grad_(True)
-    torch.nn.functional.gelu(xg).backward(torch.ones_like(xg))
-    dxg = ops.linear_dgrad(dy, w, pre=pre)
-    assert relerr(dxg.float(), dx_ref * xg.grad) < TOL[T]
+    dxg = ops.linear_dgrad(dy, w, gelu_aux=gelu_aux_of(pre))
+    assert relerr(dxg.float(), dx_ref * gelu_grad_ref(pre)) < TOL[T]
     dw = ops.linear_wgrad(dy, x)
     dw_ref = dy.double().t() @ x.double()
     assert dw.dtype == torch.float32
@@ -84,9 +105,8 @@ def test_gemm256_fast_path(M, N, K):
     ref = x.float() @ w.float().t() + b
     assert relerr(ops.linear_fwd(x, w, b, EPI_BIAS).float(), ref) < 1e-2
     assert relerr(ops.linear_fwd(x, w, b, EPI_BIAS_F32), ref) < 2e-5 * math.sqrt(K)
-    act, pre = ops.linear_gelu(x, w, b)
-    assert relerr(pre.float(), ref) < 1e-2
-    assert relerr(act.float(), torch.nn.functional.gelu(pre.float())) < 1e-2
+    act, aux = ops.linear_gelu(x, w, b)
+    check_gelu_pair(x, w, b, act, aux, 1e-2)
     resid = gen((M, N), 4)
     rowscale = gen(((M + 7) // 8,), 5).abs() + 0.5
     out = ops.linear_fwd(x, w, b, EPI_BIAS_RESID, resid=resid, rowscale=rowscale, rows_per_sample=8)
@@ -99,9 +119,7 @@ def test_gemm256_fast_path(M, N, K):
     pre2 = gen((M2, K2), 9, 1.0, T)
     dx_ref = dy.float() @ w2.float()
     assert relerr(ops.linear_dgrad(dy, w2).float(), dx_ref) < 1e-2
-    xg = pre2.float().clone().requires_grad_(True)
-    torch.nn.functional.gelu(xg).backward(torch.ones_like(xg))
-    assert relerr(ops.linear_dgrad(dy, w2, pre=pre2).float(), dx_ref * xg.grad) < 1e-2
+    assert relerr(ops.linear_dgrad(dy, w2, gelu_aux=gelu_aux_of(pre2)).float(), dx_ref * gelu_grad_ref(pre2)) < 1e-2
     dw = ops.linear_wgrad(dy, x2)
     assert relerr(dw, dy.double().t() @ x2.double()) < 1e-4
     # twice -> bit-identical (no atomics, fixed reduction order)
@@ -119,13 +137,13 @@ def test_gemm256_224_row_tile_bit_identical_to_256_row_tile(M, N, K):
     x, w, b = gen((M, K), 1, 1.0, T), gen((N, K), 2, 0.05, T), gen((N,), 3)
     resid = gen((M, N), 4)
     rowscale = gen(((M + 7) // 8,), 5).abs() + 0.5
-    dy, w2, pre2 = gen((M, N), 6, 1.0, T), gen((N, K), 7, 0.05, T), gen((M, K), 9, 1.0, T)
+    dy, w2, aux2 = gen((M, N), 6, 1.0, T), gen((N, K), 7, 0.05, T), gelu_aux_of(gen((M, K), 9, 1.0, T))
 
     def run():
-        act, pre = ops.linear_gelu(x, w, b)
-        return (ops.linear_fwd(x, w, b, EPI_BIAS), ops.linear_fwd(x, w, b, EPI_BIAS_F32), act, pre,
+        act, aux = ops.linear_gelu(x, w, b)
+        return (ops.linear_fwd(x, w, b, EPI_BIAS), ops.linear_fwd(x, w, b, EPI_BIAS_F32), act, aux,
                 ops.linear_fwd(x, w, b, EPI_BIAS_RESID, resid=resid, rowscale=rowscale, rows_per_sample=8),
-                ops.linear_dgrad(dy, w2), ops.linear_dgrad(dy, w2, pre=pre2))
+                ops.linear_dgrad(dy, w2), ops.linear_dgrad(dy, w2, gelu_aux=aux2))
     try:
         assert lib.pa_debug_set(4, 1) == 0
         ref = run()
@@ -144,25 +162,30 @@ def test_linear_dgrad_column_sums_from_the_epilogue(T, M, N, K):
     """pa_linear_dgrad(dx_colsum=...): the fc2 data-gradient GEMM dpre = (dY . W) * gelu'(pre) also returns the column sums of the dpre it
     stores (= fc1's bias gradient; used to be a separate pa_colsum pass over [R, 4D]).  bf16 big shapes take the gemm256 epilogue
     (both tile heights), the rest the generic engine + pa_colsum.  dX must be the bits of the call without the extra output; the sums
-    must equal a column sum of dX as stored (fp32 summation order aside)."""
+    must equal a column sum of dX as stored (fp32 summation order aside).  Without a GELU side input (that combination
+    used to leave the sums unwritten on the bf16 fast path) the sums come from a pa_colsum pass over the stored dX."""
     dy, w, pre = gen((M, N), 6, 1.0, T), gen((N, K), 7, 0.05, T), gen((M, K), 9, 1.0, T)
-    ref = ops.linear_dgrad(dy, w, pre=pre)
+    aux = gelu_aux_of(pre)
+    gp = aux.double() if T == torch.bfloat16 else gelu_grad_ref(pre)           # the derivative values the kernel multiplies with
+    plain = ops.linear_dgrad(dy, w)
+    csp = torch.full((K,), float("nan"), device=DEV)
+    assert torch.equal(ops.linear_dgrad(dy, w, colsum_out=csp), plain)
+    assert relerr(csp, plain.double().sum(0)) < (1e-5 if T == torch.float32 else 4e-3)
+    ref = ops.linear_dgrad(dy, w, gelu_aux=aux)
     from painter_amd._lib import lib
     try:
         for knob in (1, 2, 0):
             lib.pa_debug_set(4, knob)
             cs = torch.full((K,), float("nan"), device=DEV)
-            dx = ops.linear_dgrad(dy, w, pre=pre, colsum_out=cs)
+            dx = ops.linear_dgrad(dy, w, gelu_aux=aux, colsum_out=cs)
             assert torch.equal(dx, ref)
             want = dx.double().sum(0)                         # dx is the ROUNDED copy of what the epilogue summed: bf16 rounding noise, averaged over M rows
             tol = 1e-5 if T == torch.float32 else 4e-3
             assert relerr(cs, want) < tol, (knob, relerr(cs, want))
             assert relerr(cs, ops.colsum(dx)) < tol
-            pg = pre.double().clone().requires_grad_(True)
-            torch.nn.functional.gelu(pg).sum().backward()
-            assert relerr(cs, ((dy.double() @ w.double()) * pg.grad).sum(0)) < (2e-5 if T == torch.float32 else 2e-4)
+            assert relerr(cs, ((dy.double() @ w.double()) * gp).sum(0)) < (2e-5 if T == torch.float32 else 2e-4)
             cs2 = torch.empty_like(cs)
-            ops.linear_dgrad(dy, w, pre=pre, colsum_out=cs2)
+            ops.linear_dgrad(dy, w, gelu_aux=aux, colsum_out=cs2)
             assert torch.equal(cs, cs2)                      # fixed reduction order: bit-stable
     finally:
         lib.pa_debug_set(4, 0)
@@ -190,9 +213,12 @@ def test_gemm256_bf16_tight_gates_against_fp64(M, N, K):
     errs = {}
     errs["bias_bf16"] = _rel64(ops.linear_fwd(x, w, b, EPI_BIAS), ref)
     errs["bias_f32"] = _rel64(ops.linear_fwd(x, w, b, EPI_BIAS_F32), ref)
-    act, pre = ops.linear_gelu(x, w, b)
-    errs["gelu_pre_bf16"] = _rel64(pre, ref)
+    # act and the saved derivative against the pre-activation bits the GELU epilogue sees (= the bias epilogue's output: same operands, same
+    # accumulation order): each is one bf16 rounding + the 1.5e-7 of the erf approximation away from the fp64 function of those bits
+    act, aux = ops.linear_gelu(x, w, b)
+    pre = ops.linear_fwd(x, w, b, EPI_BIAS)
     errs["gelu_act_bf16"] = _rel64(act, torch.nn.functional.gelu(pre.double()))
+    errs["gelu_aux_bf16"] = _rel64(aux, gelu_grad_ref(pre))
     resid = gen((M, N), 4)
     rowscale = gen(((M + 1567) // 1568,), 5).abs() + 0.5
     out = ops.linear_fwd(x, w, b, EPI_BIAS_RESID, resid=resid, rowscale=rowscale, rows_per_sample=1568)
@@ -201,9 +227,8 @@ def test_gemm256_bf16_tight_gates_against_fp64(M, N, K):
     pre2 = gen((M, K), 9, 1.0, T)
     dx_ref = dy.double() @ w.double()
     errs["dgrad_bf16"] = _rel64(ops.linear_dgrad(dy, w), dx_ref)
-    xg = pre2.double().clone().requires_grad_(True)
-    torch.nn.functional.gelu(xg).backward(torch.ones_like(xg))
-    errs["dgrad_dgelu_bf16"] = _rel64(ops.linear_dgrad(dy, w, pre=pre2), dx_ref * xg.grad)
+    aux2 = gelu_aux_of(pre2)                                      # exact in bf16 like the other operands: the product is rounded once
+    errs["dgrad_dgelu_bf16"] = _rel64(ops.linear_dgrad(dy, w, gelu_aux=aux2), dx_ref * aux2.double())
     errs["wgrad_f32"] = _rel64(ops.linear_wgrad(dy, x), dy.double().t() @ x.double())
     print("gemm256 %s measured:" % ((M, N, K),), {k: "%.2e" % v for k, v in errs.items()})
     for k, v in errs.items():
@@ -516,46 +541,6 @@ def test_attn3_fused_relpos_gradient_vs_dG_gemm(B, H, Hp, Wp):
     assert float(res[2][1][nh + nw:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("B,H,Hp,Wp", [(2, 2, 56, 28), (1, 3, 16, 28), (2, 1, 24, 28)])
-def test_attn4_64_row_backward_vs_generation_3_and_fp64(B, H, Hp, Wp):
-    """Generation 4 (csrc/attn4.hip: one wave per SIMD owning two 32-row blocks, whole 8-tile groups of a head; the tiles behind them stay
-    on generation 3 with a tile offset) against generation 3 alone on the same inputs and tables, and against the fp64 reference of
-    models_painter.py:76-86 + vitdet_utils.py:96-125.  Grids: 49 tiles (6 groups + 1 tile), 14 tiles (1 group + 6 tiles in two
-    generation-3 workgroups, the second one light), 21 tiles (2 groups + 5).  Same math and the same bf16 operands, another summation
-    order: close to generation 3 (far inside the bf16 gate), bit-stable run to run."""
-    from painter_amd._lib import lib
-    L, qkv, rcat, rcatT, dout = _attn3_inputs(B, H, Hp, Wp)
-    nh, nw = 2 * Hp - 1, 2 * Wp - 1
-    out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
-    res = {}
-    try:
-        for mode in (2, 1, 2):
-            assert lib.pa_debug_set(9, mode) == 0
-            dqkv, dg = ops.attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables)
-            drcat = ops.attn_bwd_relpos(dg, qkv, rcat.shape[0], B, L, H, Hp, Wp)
-            if mode in res:
-                assert torch.equal(res[mode][0], dqkv) and torch.equal(res[mode][1], drcat)
-            res[mode] = (dqkv.clone(), drcat.clone())
-    finally:
-        lib.pa_debug_set(9, 0)
-    D = H * 64
-    e34 = dict(dq=relerr(res[2][0][:, :D].float(), res[1][0][:, :D].float()), dk=relerr(res[2][0][:, D:2 * D].float(), res[1][0][:, D:2 * D].float()),
-               dv=relerr(res[2][0][:, 2 * D:].float(), res[1][0][:, 2 * D:].float()), drel=relerr(res[2][1], res[1][1]))
-    print("generation 4 vs generation 3:", {k: "%.2e" % v for k, v in e34.items()})
-    assert max(e34.values()) < 8e-3, e34
-    q64 = qkv.double().clone().requires_grad_(True)
-    rh64 = rcat[:nh].double().clone().requires_grad_(True)
-    rw64 = rcat[nh:nh + nw].double().clone().requires_grad_(True)
-    ref, _ = attn_reference(q64, rh64, rw64, B, L, H, Hp, Wp, 0.125)
-    ref.backward(dout.double())
-    for mode in (1, 2):
-        dqkv, drcat = res[mode]
-        errs = dict(dq=relerr(dqkv[:, :D].float(), q64.grad[:, :D]), dk=relerr(dqkv[:, D:2 * D].float(), q64.grad[:, D:2 * D]),
-                    dv=relerr(dqkv[:, 2 * D:].float(), q64.grad[:, 2 * D:]), drh=relerr(drcat[:nh], rh64.grad), drw=relerr(drcat[nh:nh + nw], rw64.grad))
-        print("generation %d vs fp64:" % (2 + mode), {k: "%.2e" % v for k, v in errs.items()})
-        assert max(errs.values()) < 1.6e-2, errs
-
-
 @pytest.mark.parametrize("gen_", [0])
 def test_attn3_deterministic(gen_, attn_generation):
     attn_generation(gen_)
@@ -714,7 +699,7 @@ def test_gemm256_epilogues_bitstable_beside_concurrent_mfma_kernels():
     def once():
         act, p_ = ops.linear_gelu(x, w, b)
         out = ops.linear_fwd(x, w, b, EPI_BIAS_RESID, resid=resid, rowscale=rowscale, rows_per_sample=1568)
-        dx = ops.linear_dgrad(dy, w, pre=pre)
+        dx = ops.linear_dgrad(dy, w, gelu_aux=pre)            # (any bf16 values serve as the saved derivative here: bit-stability only)
         return act, p_, out, dx
 
     ref = once()

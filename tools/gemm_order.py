@@ -29,7 +29,7 @@ def main():
              ("qkv fwd", lambda: ops.linear_fwd(x1, w_qkv, b3, EPI_BIAS, out=o3)),
              ("proj fwd+resid", lambda: ops.linear_fwd(x1, w_proj, b1, EPI_BIAS_RESID, out=o32, resid=resid)),
              ("fc2 fwd+resid", lambda: ops.linear_fwd(x4, w_fc2, b1, EPI_BIAS_RESID, out=o32, resid=resid)),
-             ("fc2 dgrad+gelu'", lambda: ops.linear_dgrad(dy1, w_fc2, pre=hpre, out=dx4)),
+             ("fc2 dgrad+gelu'", lambda: ops.linear_dgrad(dy1, w_fc2, gelu_aux=hpre, out=dx4)),
              ("fc1 dgrad", lambda: ops.linear_dgrad(o4a, w_fc1, out=dx1)),
              ("qkv dgrad", lambda: ops.linear_dgrad(dy3, w_qkv, out=dx1)),
              ("fc1 wgrad", lambda: ops.linear_wgrad(o4a, x1, out=dw41)),

@@ -43,7 +43,7 @@ def main():
         ("qkv fwd bias  (N=3072,K=1024)", lambda: ops.linear_fwd(x1k, w3k, b3k, EPI_BIAS, out=qkv)),
         ("proj fwd resid(N=1024,K=1024)", lambda: ops.linear_fwd(x1k, w1k, b1k, EPI_BIAS_RESID, out=o32, resid=resid)),
         ("fc2 fwd resid (N=1024,K=4096)", lambda: ops.linear_fwd(x4k, w14, b1k, EPI_BIAS_RESID, out=o32, resid=resid)),
-        ("fc2 dgrad gelu(N=4096,K=1024)", lambda: ops.linear_dgrad(dy1k, w14, pre=x4k, out=dx4k)),
+        ("fc2 dgrad gelu(N=4096,K=1024)", lambda: ops.linear_dgrad(dy1k, w14, gelu_aux=x4k, out=dx4k)),
         ("fc1 dgrad     (N=1024,K=4096)", lambda: ops.linear_dgrad(x4k, w4k, out=dx1k)),
     ]
     variants = [("base", 0, 0), ("nostore", 0, 1), ("stag8k", 8000, 0), ("stag16k", 16000, 0), ("stag32k", 32000, 0)]
