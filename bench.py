@@ -29,6 +29,13 @@ all-reduce (RCCL, bucketed, overlapped with backward) is inside the step.  Print
                  /root/reference, or on the GPU box from the subset oracle/stage_ref.py staged at build time; kind "port" = the restated
                  oracle/painter_oracle.py when neither exists) on the host cores, B = 1, fp32, thread count swept over {16, 32, 64, all
                  physical cores}: value = train forward+backward images/sec at the best count, the all-cores figure beside it.
+  secondary    = the other single-GPU BASELINE configurations, measured AFTER the headline number and outside its timed region (N = 1):
+                 seggpt_n32 = BASELINE configs[3] (seggpt_vit_large_patch16_input896x448, 32 prompts over one query, feature ensemble,
+                 forward captured in a hipGraph, 5 replays), vit_huge = configs[4]'s per-GPU half (ViT-H/14 bf16, B = 4, 3 steps).
+  gradsync_variants (N > 1, under `extra`) = the same K steps timed back to back under three gradient-exchange arrangements --
+                 per-block RCCL messages from inside the backward (GradSync, the default), four coarse coalesced launches (GradSync
+                 mode "coarse"), the plain DistributedDataParallel wrapper (the reference's arrangement: no overlap with OUR backward,
+                 the floor) -- `value` is the best of them and `config.grad_allreduce` says which.
   reference_gpu = the same unmodified reference model on THIS GPU through PyTorch-ROCm eager (autocast bf16, and fp16 -- the reference's
                  literal torch.cuda.amp.autocast() -- beside it), B = 8, the bench model's parameters and batch, train forward+backward;
                  vs_reference_gpu = value / that.  A baseline leg outside every timed region of the headline number (N = 1 only).
@@ -105,14 +112,17 @@ class KernelTimer:
         "linear_dgrad": ("gemm256_dgrad", lambda a, k: _mnk(a[0].shape[0], a[0].shape[1], a[1].shape[1])),      # (dy [M,N], w [N,K])
         "linear_wgrad": ("gemm256_wgrad", lambda a, k: _mnk(a[0].shape[0], a[0].shape[1], a[1].shape[1])),      # (dy [M,N], x [M,K])
         "attn_fwd": ("attention_fwd", lambda a, k: 4.0 * a[2] * a[4] * a[3] * a[3] * a[1].shape[1]),             # (qkv, rcat [NRP, hd], batch, L, heads)
-        "attn_bwd_core": ("attention_bwd", lambda a, k: 10.0 * a[6] * a[8] * a[7] * a[7] * a[1].shape[1]),       # 2.5 x forward
+        # "recompute in flash-attention backward is not counted" -> the backward's algorithmic work is 2 x the forward's
+        # (dV, dP, dQ, dK: four L x L x hd contractions); the one unavoidable S recompute makes it 2.5 x.  `achieved` / `frac` follow 8(d);
+        # results() adds frac_with_recompute beside it.
+        "attn_bwd_core": ("attention_bwd", lambda a, k: 8.0 * a[6] * a[8] * a[7] * a[7] * a[1].shape[1]),
     }
     NAMES = {
         "gemm256_fwd": "g256::gemm256_kernel<false,false,*> (nn.Linear forward: qkv, proj, fc1+GELU, fc2, decoder_embed)",
         "gemm256_dgrad": "g256::gemm256_kernel<false,true,*> (nn.Linear data gradient dX = dY.W)",
         "gemm256_wgrad": "g256::gemm256_kernel<true,true,Epi4Slab> + slab_reduce (weight gradient dW = dY^T.X)",
         "attention_fwd": "a3::fwd_kernel (fused attention forward, rel-pos bias on the matrix pipe; head_dim 80: a2::fwd_kernel<1,1,80>)",
-        "attention_bwd": "a3::bwd_dq_kernel (rel-pos table gradient contracted inside) + a3::bwd_dkv_kernel + prep_delta (fused attention backward, 2.5x the forward's FLOPs; head_dim 80: a2::bwd_dq_kernel<2,2,80,WP32> + a2::bwd_dkv_kernel<2,80> + delta)",
+        "attention_bwd": "a3::bwd_dq_kernel (rel-pos table gradient contracted inside) + a3::bwd_dkv_kernel + prep_delta (fused attention backward; head_dim 80: a2::bwd_dq_kernel<2,2,80,WP32> + a2::bwd_dkv_kernel<2,80> + delta)",
     }
 
     def __init__(self, ops_mod):
@@ -150,7 +160,121 @@ class KernelTimer:
             tf = ent["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
             out[fam] = {"kernel": self.NAMES[fam], "launches": n, "kernel_ms_total": round(ms, 3), "avg_us": round(ms / max(n, 1) * 1e3, 2),
                         "achieved": round(tf, 2), "frac": round(tf / peak, 4)}
+            if fam == "attention_bwd":
+                out[fam].update({"frac_8d": round(tf / peak, 4), "frac_with_recompute": round(1.25 * tf / peak, 4),
+                                 "accounting": "frac = frac_8d: 2 x the forward's FLOPs (SURVEY.md 8d: recompute not counted); frac_with_recompute: 2.5 x (the one S recompute a flash backward needs)"})
         return out
+
+
+# Algorithmic HBM bytes per launch of the kernels profiles/roofline_traffic.json holds (ViT-L, B = 8: R = 12544 token rows, D = 1024, hidden
+# 4096, 128 (sample, head) pairs of 1568 tokens x 64; bf16 operands): every operand read once, every output written once.
+def _algorithmic_bytes():
+    R, D, Hd, L, BH, hd = 12544, 1024, 4096, 1568, 128, 64
+    qkv = BH * L * hd * 2                                        # one of q / k / v, all heads: 25.7 MB
+    tables = BH * (L // 32) * 6144                               # per-query bias tables of generation 3: 38.5 MB
+    return {
+        "fc1": {"bytes": R * D * 2 + Hd * D * 2 + 2 * R * Hd * 2, "what": "X [R, D] + W [4D, D] in; act + gelu' [R, 4D] out"},
+        "wgrad": {"bytes": R * Hd * 2 + R * D * 2 + 4 * Hd * D, "what": "fc1 / fc2 weight gradient: dY [R, 4D] + X [R, D] in; dW fp32 [4D, D] out (split-K slabs and their reduction are overhead, not algorithm)"},
+        "dgrad": {"bytes": R * D * 2 * 2 + D * D * 2, "what": "proj data gradient: dY [R, D] + W [D, D] in; dX [R, D] out (the family's most frequent instantiation)"},
+        "attn_fwd": {"bytes": 3 * qkv + qkv + BH * L * 4 + tables, "what": "q, k, v in; out, lse, bias tables (kept for the backward) out"},
+        "attn_bwd_dq": {"bytes": 3 * qkv + qkv + tables + qkv, "what": "q, k, v, dO, tables in; dQ out (+ the [166, 64] table gradient)"},
+        "attn_bwd_dkv": {"bytes": 3 * qkv + qkv + tables + 2 * qkv, "what": "q, k, v, dO, tables in; dK, dV out"},
+    }
+
+
+def secondary_seggpt_n32(dev, replays=5):
+    """BASELINE configs[3]: seggpt_vit_large_patch16_input896x448, N = 32 prompts sharing one query (merge_between_batch = 0, seg_type ones,
+    bottom-half mask as [1, L]: seggpt_engine.py:36-47), bf16, forward only, captured in a hipGraph and replayed (tools/seggpt_bench.py is
+    the long form with the reference-on-GPU leg).  Parameters are drawn on the device (a secondary leg has a ~10 s budget)."""
+    from painter_amd import models_seggpt
+    N = 32
+    m = models_seggpt.seggpt_vit_large_patch16_input896x448(compute_dtype="bf16").to(dev).eval()
+    _randomize_on_device(m, 1)
+    c = m._cfg
+    imgs, tgts, _, valid = synthetic_inputs(N, c.H, c.W, c.L, 1234, dev)
+    imgs[:, :, c.H // 2:] = imgs[:1, :, c.H // 2:]
+    mask = torch.zeros((1, c.L), dtype=torch.float32, device=dev)
+    mask[:, c.L // 2:] = 1
+    seg_type = torch.ones((N, 1), device=dev)
+
+    def fwd():
+        with torch.no_grad():
+            return m(imgs, tgts, mask, valid, seg_type, 0)
+    loss, pred, _ = fwd()
+    torch.cuda.synchronize()
+    ref_pred = pred.clone()
+    cap = torch.cuda.Stream()
+    cap.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cap):
+        fwd()                                  # warm-up on the capture stream (per-stream workspaces)
+    torch.cuda.current_stream().wait_stream(cap)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=cap):
+        _, g_pred, _ = fwd()
+    graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(replays):
+        graph.replay()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / replays
+    res = {"value": round(N / t, 2), "unit": "images/sec", "ms_per_forward": round(t * 1e3, 3), "prompts": N, "dtype": "bf16",
+           "tflops": round(N * 1.5897 / t, 1), "frac_whole_model": round(N * 1.5897 / t / PEAK_BF16_TFLOPS, 4),
+           "replay_equals_eager": bool(torch.equal(g_pred, ref_pred)), "loss": round(float(loss), 6),
+           "workload": "seggpt_vit_large_patch16_input896x448 inference, batch=32 in-context prompts, 1xMI355X, forward-only hipGraph replay x%d (BASELINE configs[3])" % replays}
+    del graph, m
+    torch.cuda.empty_cache()
+    return res
+
+
+def secondary_vit_huge(dev, steps=3, batch=4):
+    """BASELINE configs[4], the per-GPU half: painter_vit_huge_patch14_input896x448 (class constructor at ViT-H/14 sizes), bf16, B = 4,
+    train mode, forward + backward (`bench.py --model vit_huge` is the long form with the per-family table)."""
+    from painter_amd import models_painter
+    spec = MODELS["vit_huge"]
+    m = getattr(models_painter, spec["factory"])(compute_dtype="bf16").to(dev).train()
+    _randomize_on_device(m, 1)
+    c = m._cfg
+    imgs, tgts, mask, valid = synthetic_inputs(batch, c.H, c.W, c.L, 1234, dev)
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        loss, _, _ = m(imgs, tgts, bool_masked_pos=mask, valid=valid)
+        loss.backward()
+        return loss
+    step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    ips = batch / t
+    res = {"value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(t * 1e3, 2), "batch": batch, "steps": steps, "dtype": "bf16",
+           "frac": round(ips * spec["blocks"] / 1e12 / PEAK_BF16_TFLOPS, 4), "whole_model_frac": round(ips * spec["whole"] / 1e12 / PEAK_BF16_TFLOPS, 4),
+           "loss": round(float(loss), 6), "workload": spec["workload"] % ("bf16", batch, 1)}
+    del m
+    torch.cuda.empty_cache()
+    return res
+
+
+def _randomize_on_device(model, seed):
+    """randomize_parameters() with the draws made on the device (the secondary legs build 0.37 / 0.63 G-parameter models inside a ~10 s
+    budget; the HEADLINE model keeps the host-RNG recipe so that its line is comparable across rounds)."""
+    g = torch.Generator(device=next(model.parameters()).device).manual_seed(seed)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            r = torch.randn(p.shape, generator=g, device=p.device)
+            if n.endswith("norm1.weight") or n.endswith("norm2.weight") or n in ("norm.weight", "decoder_pred.1.weight"):
+                p.copy_(1.0 + 0.1 * r)
+            elif n.endswith("rel_pos_h") or n.endswith("rel_pos_w"):
+                p.copy_(0.05 * r)
+            elif p.ndim == 4 and p.shape[-1] > 1:
+                p.copy_(r / (p.shape[1] * p.shape[2] * p.shape[3]) ** 0.5)
+            else:
+                p.copy_(0.02 * r)
 
 
 def cpu_baseline(budget_s=100.0):
@@ -432,6 +556,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-gpu", action="store_true", help="skip the reference-on-this-GPU leg (unmodified reference model, PyTorch eager)")
     ap.add_argument("--no-optimizer", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (SegGPT N = 32 hipGraph, ViT-H/14 B = 4) after the headline measurement")
+    ap.add_argument("--gradsync", default="all", choices=["all", "per_block", "coarse", "ddp"],
+                    help="N > 1: which gradient-exchange arrangement(s) to time (all = the three back to back, value = the best)")
     ap.add_argument("--eval", action="store_true", help="eval mode (no DropPath)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = DEBUG: run the N > 1 branch (relaunch, parameter broadcast, GradSync inside the backward, MAX-reduced timing) "
@@ -468,47 +595,73 @@ def main():
     model.train(not args.eval)
     if distributed:
         parallel.broadcast_parameters(model)                # ... and adopt rank 0's parameters, as under the DDP wrapper
-        model.grad_sync = parallel.GradSync()
     cfg = model._cfg
     imgs, tgts, mask, valid = synthetic_inputs(args.batch, cfg.H, cfg.W, cfg.L, 1234 + rank, dev)
+    net = [model]                                            # what step() calls: the bare module, or the DDP wrapper around it
 
     def step():
         for p in model.parameters():
             p.grad = None
-        loss, _, _ = model(imgs, tgts, bool_masked_pos=mask, valid=valid)
+        loss, _, _ = net[0](imgs, tgts, bool_masked_pos=mask, valid=valid)
         loss.backward()
         return loss
 
     timer = KernelTimer(ops)
     timer.install()                                          # inert (one attribute test per op call) until .active is set
-    for _ in range(args.warmup):
-        step()
 
     def barrier():
         if distributed:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
-    lossv = float(loss.item())
-    n_ranks = world
-    if distributed:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-        n_ranks = torch.distributed.get_world_size()
+    def timed_region():
+        """W untimed warm-up steps, then EXACTLY K steps between barriers; -> (seconds = MAX over ranks, last loss)."""
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if distributed:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, float(loss.item())
+
+    # N > 1: the gradient exchange is the only thing an 8-GPU node adds, and it has never met real RCCL ranks -- so the same K steps are
+    # timed under three arrangements back to back and the line reports all of them (extra.gradsync_variants); `value` is the best one.
+    #   per_block  GradSync as the engine drives it: ~125 asynchronous RCCL collectives per step from inside the backward, reverse layer order
+    #   coarse     GradSync(mode="coarse"): the same gradients in four coalesced launches (400 MB each)
+    #   ddp        the plain DistributedDataParallel wrapper (the reference's own arrangement, main_train.py:340): its reducer only sees
+    #              the gradients when our autograd node returns them all at once, i.e. NO overlap with the backward -- the floor
+    n_ranks = torch.distributed.get_world_size() if distributed else 1
+    variants = {}
+    arrangement = "n/a"
+    if not distributed:
+        dt, lossv = timed_region()
+    else:
+        todo = ["per_block", "coarse", "ddp"] if args.gradsync == "all" else [args.gradsync]
+        for name in [v for v in todo if v != "ddp"]:
+            model.grad_sync = parallel.GradSync(mode=name)
+            d_, l_ = timed_region()
+            variants[name] = {"seconds": d_, "loss": l_, "collective_launches_per_step": model.grad_sync.launches // (args.steps + args.warmup)}
+        gs_best = min((v for v in variants), key=lambda v: variants[v]["seconds"]) if variants else None
+
+    # ---- sustained region (below) runs under the better GradSync arrangement; the DDP wrapper is timed after it (its reducer hooks stay on
+    # the parameters for the life of the wrapper, so it goes last)
+    if distributed and gs_best is not None:
+        model.grad_sync = parallel.GradSync(mode=gs_best)
 
     # ---- sustained region: the same step until --min-seconds have gone by (every rank runs the same number of steps, fixed
     # beforehand from the first region's pace, so the collectives stay matched); `value` above stays the exactly-K-steps number
     sustained = None
     clock_power = None
-    if args.min_seconds > 0:
+    if distributed:
+        dt = variants[gs_best]["seconds"] if gs_best is not None else None
+    if args.min_seconds > 0 and dt is not None:
         n_sus = max(args.steps, int(args.min_seconds / (dt / args.steps)) + 1)
         sampler = ClockPowerSampler() if rank == 0 else None
         barrier()
@@ -528,6 +681,21 @@ def main():
             dts = float(t.item())
         sustained = {"steps": n_sus, "seconds": round(dts, 3), "value": round(n_ranks * args.batch * n_sus / dts, 3),
                      "ms_per_step": round(dts / n_sus * 1e3, 3)}
+        if distributed:
+            sustained["gradsync"] = gs_best
+
+    if distributed:
+        if args.gradsync in ("all", "ddp"):
+            model.grad_sync = None
+            net[0] = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index] if args.backend == "nccl" else None)
+            d_, l_ = timed_region()
+            variants["ddp"] = {"seconds": d_, "loss": l_}
+        arrangement = min(variants, key=lambda v: variants[v]["seconds"])
+        dt, lossv = variants[arrangement]["seconds"], variants[arrangement]["loss"]
+        for v in variants.values():
+            v["value"] = round(n_ranks * args.batch * args.steps / v["seconds"], 3)
+            v["ms_per_step"] = round(v["seconds"] / args.steps * 1e3, 3)
+            v["seconds"] = round(v["seconds"], 4)
 
     # ---- separate profiled pass (never compare a profiled arm with an un-profiled one: `value` above is un-instrumented)
     kernels = {}
@@ -539,6 +707,7 @@ def main():
         # ... and the parameter-gradient kernels get the sizing they have when they own the chip (the engine sizes them for HALF the chip
         # because they normally run beside the data-gradient chain: timed alone at that size they looked 30 % slower than the
         # one-stream rocprof summary under profiles/, which is taken with PAINTER_AMD_SIDE_STREAM=0, i.e. full-chip sizing)
+        knobs = {k: _lib.pa_debug_get(k) for k in (3, 6)}      # restored below to what was in effect, not re-derived
         _lib.pa_debug_set(3, 0)
         _lib.pa_debug_set(6, 0)
         step()
@@ -548,10 +717,8 @@ def main():
         torch.cuda.synchronize()
         timer.active = False
         model._hot.use_side_stream = side
-        if side:
-            from painter_amd import engine as _engine
-            _lib.pa_debug_set(3, _engine.WGRAD_SIDE_TARGET)
-            _lib.pa_debug_set(6, _engine.RELPOS_SIDE_SPLITS)
+        for k, v in knobs.items():
+            _lib.pa_debug_set(k, v)
         peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
         kernels = timer.results(peak)
         for v in kernels.values():
@@ -564,8 +731,13 @@ def main():
         launch_check = {fam: {"launches": kernels.get(fam, {}).get("launches", 0), "expected": w_}
                         for fam, w_ in (("gemm256_fwd", want), ("gemm256_dgrad", want), ("gemm256_wgrad", want + extra_w))}
         bad = {f: v for f, v in launch_check.items() if v["launches"] != v["expected"]}
-        if bad:                                             # recorded, not fatal: the headline number above is already measured
-            print("bench.py: unexpected launch counts in the profiled pass: %s" % bad, file=sys.stderr)
+        if bad:
+            # a dispatch regression (GEMMs falling off the gemm256 path, a double-counted bracket): the per-family table would be
+            # computed over the wrong launch set, so it is WITHHELD (roofline.kernels / dominant_kernel = null) and the process exits
+            # non-zero after printing the line -- the headline number above is already measured and stays in it
+            print("bench.py: unexpected launch counts in the profiled pass, per-family table withheld: %s" % bad, file=sys.stderr)
+            launch_check["mismatch"] = True
+            kernels = {}
 
     if rank == 0:
         ips = n_ranks * args.batch * args.steps / dt
@@ -591,6 +763,13 @@ def main():
                                                % (meta.get("lib_sha16"), _lib_sha16())}
             except Exception:
                 traffic = None
+        traffic_by_family = None
+        if traffic_meta is not None and "refused" not in traffic_meta:
+            alg = _algorithmic_bytes()
+            traffic_by_family = {k: {"hbm_bytes_per_launch": tj[k]["hbm_bytes_per_launch"], "hbm_read_bytes": tj[k].get("hbm_read_bytes"),
+                                     "hbm_write_bytes": tj[k].get("hbm_write_bytes"), "algorithmic_bytes_per_launch": alg[k]["bytes"],
+                                     "ratio": round(tj[k]["hbm_bytes_per_launch"] / alg[k]["bytes"], 2), "algorithmic": alg[k]["what"]}
+                                 for k in alg if k in tj}
         achieved = ips / n_ranks * spec["blocks"] / 1e12
         out = {
             "metric": "images/sec (896x448 pairs) %s fwd+bwd" % ("ViT-L" if args.model == "vit_large" else "ViT-H/14"),
@@ -603,13 +782,15 @@ def main():
                        "rccl_ranks": n_ranks if (distributed and args.backend == "nccl") else 0,
                        "backend": (args.backend if args.backend == "nccl" else "gloo -- DEBUG arrangement: %d ranks on %d visible GPU(s); not a scaling number" % (n_ranks, n_dev)) if distributed else "n/a",
                        "taps": list(cfg.taps),
-                       "grad_allreduce": "RCCL bucketed, overlapped with backward" if n_ranks > 1 else "n/a"},
+                       "grad_allreduce": {"per_block": "RCCL, one message per weight matrix + one flat message per block, started from inside the backward (GradSync)",
+                                          "coarse": "RCCL, four coalesced launches of ~400 MB from inside the backward (GradSync mode coarse)",
+                                          "ddp": "torch DistributedDataParallel wrapper (the reference's arrangement; no overlap with the HIP backward)"}.get(arrangement, "n/a")},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "definition": "images/s/GPU x %.3f TFLOP (attention + MLP blocks, fwd+bwd; SURVEY.md 8d) / dense bf16 MFMA peak" % (spec["blocks"] / 1e12),
                          "whole_model_achieved": round(ips / n_ranks * spec["whole"] / 1e12, 2),
                          "whole_model_frac": round(ips / n_ranks * spec["whole"] / 1e12 / peak, 4),
                          "traffic": traffic, "traffic_source": "profiles/roofline_traffic.json (rocprofv3 PMC passes of this bench on this library, tools/pmc_traffic.py; not re-measured inside this run)" if traffic is not None else None,
-                         "traffic_meta": traffic_meta, "launch_count_check": launch_check,
+                         "traffic_meta": traffic_meta, "traffic_by_family": traffic_by_family, "launch_count_check": launch_check,
                          "dominant_kernel": dominant, "kernels": kernels,
                          "profiled_pass": "separate pass of %d steps after the timed region, HIP events per launch, one stream, parameter-gradient kernels sized for the whole chip (as in profiles/*one_stream_kernel_stats.csv)" % args.profile_steps},
             "loss": round(lossv, 6),
@@ -617,8 +798,20 @@ def main():
             "extra": clock_power,
             "build": {"git_head": _git_head(), "lib_sha16": _lib_sha16()},
         }
+        if variants:
+            out["extra"] = dict(out["extra"] or {}, gradsync_variants=variants, gradsync_chosen=arrangement)
         if n_ranks == 1 and args.dtype == "bf16" and not args.no_optimizer and args.model == "vit_large":
             out["optimizer_step"] = optimizer_step_ms(model, step)
+        if n_ranks == 1 and not distributed and args.dtype == "bf16" and args.model == "vit_large" and not args.no_secondary:
+            # the other single-GPU BASELINE configurations, after (never inside) the headline measurement; each a few seconds
+            out["secondary"] = {}
+            for key, fn in (("seggpt_n32", secondary_seggpt_n32), ("vit_huge", secondary_vit_huge)):
+                try:
+                    t0 = time.perf_counter()
+                    out["secondary"][key] = fn(dev)
+                    out["secondary"][key]["leg_seconds"] = round(time.perf_counter() - t0, 1)
+                except Exception as e:                  # a secondary leg never takes the line down
+                    out["secondary"][key] = {"error": "%s: %s" % (type(e).__name__, e)}
         if n_ranks == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         if n_ranks == 1 and not args.no_reference_gpu and args.model == "vit_large" and not args.eval:
@@ -634,6 +827,8 @@ def main():
     if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if launch_check is not None and launch_check.get("mismatch"):
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

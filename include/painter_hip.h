@@ -47,6 +47,7 @@ int pa_abi_version(void);
  * rel-pos table-gradient GEMM; 7 = rel-pos table gradient inside the generation-3 dQ kernel: 0 default (on), 1 off, 2 on (tests);
  * 8 = generation-3 attention: workgroups with idle waves dispatched last: 0 default (on), 1 off, 2 on. */
 int pa_debug_set(int which, int value);
+int pa_debug_get(int which);      /* the value last set (-1: no such knob) -- callers that change a knob temporarily restore what they found */
 
 /* ---- nn.Linear: y = x W^T + b.  models_painter.py:76 (qkv), :87 (proj), timm Mlp fc1/fc2 (:201,:230) ----
  * PA_EPI_BIAS_GELU: out = gelu(pre), pre = x W^T + b rounded to T; out2 (optional, T [M,N] ld=ldo) receives what the backward needs of
@@ -108,6 +109,9 @@ int64_t pa_attn_tables_bytes(int dtype, int batch, int L, int heads, int Hp, int
 /* 0 = default kernels for the grid (generation 3 where it applies), 3 = the same explicitly, 2 = never use the 28-token-wide
  * generation-3 kernels (diagnostics, A/B, cross-generation tests) */
 int pa_attn_set_generation(int generation);
+/* diagnostics / tests: host-side launch counts since process start, out6 = {pa_attn_fwd on the generic kernels (csrc/attn_fwd.hip),
+ * on generation 2 (attn2.hip: every head_dim-80 grid with key rows of 12..32 tokens), on generation 3 (attn3.hip), pa_attn_bwd likewise} */
+int pa_attn_launch_counts(long long* out6);
 /* diagnostics: enable != 0 runs the generation-3 dQ kernel with s_memtime stamps (two workgroups, waves 0 / 1, 64 tiles, 8 slots);
  * host_out (may be NULL) receives the 2 x 2 x 64 x 8 stamps of the last traced launch */
 int pa_attn_trace(int enable, unsigned long long* host_out);

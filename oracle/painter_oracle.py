@@ -400,6 +400,16 @@ def h14_small_config(depth: int = 16) -> OracleConfig:
                         taps=generalised_taps(depth))
 
 
+def h14_grid_config(which: str) -> OracleConfig:
+    """ViT-H/14 ARITHMETIC (patch 14, head_dim 80 = embed 160 / 2 heads, depth 24 so that the unmodified reference can run it) on token
+    grids wide enough for the kernels bench.py --model vit_huge times (csrc/attn2.hip, head_dim-80 instantiation: key rows of 12..32
+    tokens; h14_small_config's 8 x 4 grid runs on the generic kernels):
+      "w12": 336 x 168 -> 24 x 12 tokens (key rows of 12);  "w32": 896 x 448 -> 64 x 32 tokens, ViT-H/14's own grid (key row = one 32-key
+      tile, the WP32 code path).  Golden vectors: tests/golden/painter_h14_grids.npz (make_golden.py --h14-grids)."""
+    img = {"w12": (336, 168), "w32": (896, 448)}[which]
+    return OracleConfig(img_size=img, patch_size=14, embed_dim=160, depth=24, num_heads=2, decoder_embed_dim=64, taps=generalised_taps(24))
+
+
 def vit_huge_config() -> OracleConfig:
     """BASELINE configs[4] / SURVEY.md 8d config 5: ViT-H/14 through the class constructor (models_painter.py:241-266) -- patch 14,
     embed 1280, depth 32, 16 heads (head_dim 80), 64 x 32 tokens.  NOT a reference factory; taps generalised."""

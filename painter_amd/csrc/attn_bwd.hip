@@ -535,13 +535,17 @@ extern "C" int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* 
     if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4 || (head_dim != 64 && head_dim != 80)) return (int)hipErrorInvalidValue;
     if (dtype == PA_BF16 && head_dim == ATT_HD && tables != nullptr && attn3_ok(L, Hp, Wp)) {
         if (relpos_part != nullptr && attn3_relpos_partials_bytes(batch, L, heads, Hp, Wp) == 0) return (int)hipErrorInvalidValue;
+        ++g_attn_counts[5];
         return attn3_bwd((const bf16*)qkv, ldq, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, tables, (bf16*)dqkv, (bf16*)dG,
                          (float*)relpos_part, batch, L, heads, Hp, Wp, scale, st);
     }
     if (relpos_part != nullptr || dG == nullptr || delta == nullptr) return (int)hipErrorInvalidValue;      // only the generation-3 kernels fuse the rel-pos gradient / read Delta from the tables
-    if (dtype == PA_BF16 && attn2_ok(L, Hp, Wp, head_dim))
+    if (dtype == PA_BF16 && attn2_ok(L, Hp, Wp, head_dim)) {
+        ++g_attn_counts[4];
         return attn2_bwd((const bf16*)qkv, ldq, (const bf16*)rcat, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, (bf16*)dqkv,
                          (bf16*)dG, aux, batch, L, heads, Hp, Wp, head_dim, scale, st);
+    }
+    ++g_attn_counts[3];
 #define PA_ATTN_BWD(TT_, HD_) attn_bwd_t<TT_, HD_>((const TT_*)qkv, ldq, (const TT_*)rcat, (const TT_*)rcatT, (const TT_*)dout, lddo, lse, delta, \
                                                    (TT_*)dqkv, (TT_*)dG, (float*)aux, batch, L, heads, Hp, Wp, scale, st)
     if (dtype == PA_BF16) return head_dim == 80 ? PA_ATTN_BWD(bf16, 80) : PA_ATTN_BWD(bf16, 64);

@@ -238,10 +238,15 @@ extern "C" int64_t pa_attn_tables_bytes(int dtype, int batch, int L, int heads, 
 extern "C" int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void* out, int64_t ldo, float* lse, void* tables,
                            int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t st) {
     if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4 || !head_dim_ok(head_dim)) return (int)hipErrorInvalidValue;
-    if (dtype == PA_BF16 && head_dim == ATT_HD && attn3_ok(L, Hp, Wp))
+    if (dtype == PA_BF16 && head_dim == ATT_HD && attn3_ok(L, Hp, Wp)) {
+        ++g_attn_counts[2];
         return attn3_fwd((const bf16*)qkv, ldq, (const bf16*)rcat, (bf16*)out, ldo, lse, tables, batch, L, heads, Hp, Wp, scale, st);
-    if (dtype == PA_BF16 && attn2_ok(L, Hp, Wp, head_dim))
+    }
+    if (dtype == PA_BF16 && attn2_ok(L, Hp, Wp, head_dim)) {
+        ++g_attn_counts[1];
         return attn2_fwd((const bf16*)qkv, ldq, (const bf16*)rcat, (bf16*)out, ldo, lse, batch, L, heads, Hp, Wp, head_dim, scale, st);
+    }
+    ++g_attn_counts[0];
     if (dtype == PA_BF16) return attn_fwd_t<bf16>(qkv, ldq, rcat, out, ldo, lse, batch, L, heads, Hp, Wp, head_dim, scale, st);
     return attn_fwd_t<float>(qkv, ldq, rcat, out, ldo, lse, batch, L, heads, Hp, Wp, head_dim, scale, st);
 }

@@ -122,6 +122,11 @@ inline int g_attn3_fuse = 0;
 // pa_debug_set(8, v): 0 = default (light attention workgroups dispatched last unless PA_ATTN_LIGHT_LAST=0), 1 = off, 2 = on
 inline int g_attn_light_last = 0;
 
+// host-side launch counters of the attention entry points, by kernel family: [0..2] pa_attn_fwd on the generic (attn_fwd.hip) /
+// generation-2 (attn2.hip) / generation-3 (attn3.hip) kernels, [3..5] pa_attn_bwd likewise (pa_attn_launch_counts; the model-level tests
+// assert with them WHICH kernels a configuration ran on)
+inline long long g_attn_counts[6] = {0, 0, 0, 0, 0, 0};
+
 // exact (erf) GELU and its derivative -- nn.GELU default (Painter/models_painter.py:253)
 DEVI float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 DEVI float gelu_grad_f(float x) {

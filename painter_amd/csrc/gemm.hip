@@ -532,6 +532,13 @@ extern "C" int pa_linear_wgrad(int dtype, const void* dy, int64_t lddy, const vo
 }
 
 extern "C" int pa_abi_version(void) { return PA_ABI_VERSION; }
+extern "C" int pa_debug_get(int which) {
+    if (which < 0 || which > 8) return -1;
+    if (which == 6) return g_relpos_splits;
+    if (which == 7) return g_attn3_fuse;
+    if (which == 8) return g_attn_light_last;
+    return g256::g_dbg[which];
+}
 extern "C" int pa_debug_set(int which, int value) {
     if (which < 0 || which > 8) return (int)hipErrorInvalidValue;
     if (which < 8) g256::g_dbg[which] = value;

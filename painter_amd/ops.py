@@ -192,6 +192,16 @@ def attn_fwd(qkv, rcat, batch, L, heads, Hp, Wp, scale, need_tables=False):
     return (out, lse, tables) if need_tables else (out, lse)
 
 
+def attn_launch_counts():
+    """-> {"fwd": (generic, generation 2, generation 3), "bwd": (...)}: host-side launch counts of pa_attn_fwd / pa_attn_bwd by kernel family
+    since process start (tests assert with them which kernels a model configuration actually ran on)."""
+    import ctypes
+    buf = (ctypes.c_longlong * 6)()
+    check(lib.pa_attn_launch_counts(ctypes.addressof(buf)), "pa_attn_launch_counts")
+    v = [int(x) for x in buf]
+    return {"fwd": tuple(v[:3]), "bwd": tuple(v[3:])}
+
+
 def relpos_pack_t(rel_pos_h, rel_pos_w, Hp, Wp, dtype):
     nrp = lib.pa_relpos_rows_padded(Hp, Wp)
     hd = rel_pos_h.shape[1]

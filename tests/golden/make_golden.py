@@ -93,7 +93,7 @@ def grad_digest(named_grads, out: dict, prefix: str):
     out[prefix + "grad_sample_stride"] = np.int64(GRAD_STRIDE)
 
 
-def case_painter(cfg, out, prefix, batch, mask_kind, seed_p=1, seed_x=1234, backward=True, train_mode=False):
+def case_painter(cfg, out, prefix, batch, mask_kind, seed_p=1, seed_x=1234, backward=True, train_mode=False, pred_stride=0):
     model, _ = build_reference(cfg, seed_p)
     imgs, tgts, mask, valid = O.synthetic_batch(cfg, batch, seed_x, mask_kind)
     if train_mode:
@@ -117,8 +117,15 @@ def case_painter(cfg, out, prefix, batch, mask_kind, seed_p=1, seed_x=1234, back
         p.grad = None
     loss, pred, m = model(imgs, tgts, bool_masked_pos=mask.reshape(batch, *cfg.grid), valid=valid)
     out[prefix + "loss"] = np.float64(loss.item())
-    out[prefix + "pred"] = pred.detach().numpy()
-    out[prefix + "mask_out"] = m.numpy()
+    if pred_stride:         # big grids: a strided sample + the norm instead of the tensor (as the ViT-L fixtures do)
+        flat = pred.detach().reshape(-1)
+        out[prefix + "pred_sample"] = flat[::pred_stride].numpy()
+        out[prefix + "pred_stride"] = np.int64(pred_stride)
+        out[prefix + "pred_norm"] = np.float64(flat.double().norm().item())
+        out[prefix + "mask_out_sum"] = np.float64(m.double().sum().item())
+    else:
+        out[prefix + "pred"] = pred.detach().numpy()
+        out[prefix + "mask_out"] = m.numpy()
     out[prefix + "valid_out_sum"] = np.float64(valid.double().sum().item())
     if backward:
         loss.backward()
@@ -269,6 +276,16 @@ def case_h14(out):
     case_painter(cfg, out, "h14_train/", batch=2, mask_kind="half", seed_p=32, seed_x=42, train_mode=True)
 
 
+def case_h14_grids(out):
+    """The head_dim-80 / patch-14 arithmetic on the token grids whose attention runs on the kernels `bench.py --model vit_huge` times
+    (csrc/attn2.hip<..., 80>: key rows of 12..28 tokens, and exactly 32 = the WP32 path of ViT-H/14's own 64 x 32 grid) -- the 8 x 4
+    grid of case_h14 routes to the generic kernels.  UNMODIFIED reference, depth 24 (its hard-coded taps), eval and train mode."""
+    w12, w32 = O.h14_grid_config("w12"), O.h14_grid_config("w32")
+    case_painter(w12, out, "h14_w12/", batch=2, mask_kind="random", seed_p=34, seed_x=44, pred_stride=7)
+    case_painter(w12, out, "h14_w12_train/", batch=2, mask_kind="half", seed_p=35, seed_x=45, train_mode=True, pred_stride=7)
+    case_painter(w32, out, "h14_w32/", batch=1, mask_kind="random", seed_p=36, seed_x=46, pred_stride=37)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true", help="also generate the ViT-L 896x448 fixture")
@@ -277,6 +294,7 @@ def main():
     ap.add_argument("--vitl-b8", action="store_true", help="only: ViT-L B=8 train-mode fixture (8 B=1 runs of the reference, ~3 min, 15 GB)")
     ap.add_argument("--seggpt-n32", action="store_true", help="only: SegGPT ViT-L N=32 feature-ensemble forward (~6 min)")
     ap.add_argument("--h14", action="store_true", help="only: the head_dim 80 / patch 14 small fixture (seconds)")
+    ap.add_argument("--h14-grids", action="store_true", help="only: head_dim 80 / patch 14 on the 24 x 12 and 64 x 32 token grids (the timed attn2<80> kernels)")
     ap.add_argument("--vitl-b1", action="store_true", help="only: ViT-L B=1 eval fixture (~2 min)")
     args = ap.parse_args()
     torch.set_num_threads(os.cpu_count())
@@ -291,6 +309,12 @@ def main():
         case_h14(out)
         np.savez_compressed(os.path.join(HERE, "painter_h14.npz"), **out)
         print("painter_h14.npz", {k: v for k, v in out.items() if k.endswith("loss")})
+        return
+    if args.h14_grids:
+        out = {}
+        case_h14_grids(out)
+        np.savez_compressed(os.path.join(HERE, "painter_h14_grids.npz"), **out)
+        print("painter_h14_grids.npz", {k: v for k, v in out.items() if k.endswith("loss")})
         return
     if args.vitl_b1:
         args.full = True

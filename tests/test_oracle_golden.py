@@ -37,6 +37,33 @@ def test_oracle_matches_reference_golden_painter(fixture, case, batch, mask_kind
     G.check_grad_digests(fx, case, [(k, v.grad) for k, v in P.items()], 1e-4, 1e-5, 1e-4)
 
 
+def check_pred_sample(fx, case, pred, tol, fro=False):
+    """pred against a fixture that stores a strided sample + the norm of the flattened tensor (big grids)."""
+    flat = torch.as_tensor(pred).detach().float().cpu().reshape(-1)
+    stride = int(fx[case + "pred_stride"])
+    e = (G.rel_fro if fro else G.rel_err)(flat[::stride], fx[case + "pred_sample"])
+    assert e < tol, e
+    assert abs(float(flat.double().norm()) - float(fx[case + "pred_norm"])) < max(tol, 1e-5) * float(fx[case + "pred_norm"])
+    return e
+
+
+@pytest.mark.parametrize("which,case,batch,seed_p,seed_x", [("w12", "h14_w12/", 2, 34, 44), ("w32", "h14_w32/", 1, 36, 46)])
+def test_oracle_matches_reference_golden_h14_grids(which, case, batch, seed_p, seed_x):
+    """The head_dim-80 / patch-14 fixtures on the 24 x 12 and 64 x 32 token grids (tests/golden/painter_h14_grids.npz, the unmodified
+    reference at depth 24): the oracle reproduces loss, the pred sample, the mask count and every gradient digest."""
+    fx = G.load("painter_h14_grids.npz")
+    cfg = O.h14_grid_config(which)
+    P = {k: v.clone().requires_grad_(True) for k, v in O.random_params(cfg, seed_p).items()}
+    imgs, tgts, mask, valid = O.synthetic_batch(cfg, batch, seed_x, "random")
+    loss, pred, m = O.forward(P, cfg, imgs, tgts, mask.reshape(batch, *cfg.grid), valid)
+    assert abs(loss.item() - float(fx[case + "loss"])) <= 2e-6 * abs(float(fx[case + "loss"]))
+    check_pred_sample(fx, case, pred, 1e-5)
+    assert m.double().sum().item() == float(fx[case + "mask_out_sum"])
+    assert valid.double().sum().item() == float(fx[case + "valid_out_sum"])
+    loss.backward()
+    G.check_grad_digests(fx, case, [(k, v.grad) for k, v in P.items()], 1e-4, 1e-5, 1e-4)
+
+
 @pytest.mark.parametrize("fixture,case,seed_p,seed_x,mask_kind", [("painter_tiny.npz", "painter_train/", 5, 11, "random"),
                                                                   ("painter_h14.npz", "h14_train/", 32, 42, "half")])
 def test_oracle_train_mode_droppath_matches_reference(fixture, case, seed_p, seed_x, mask_kind):

@@ -33,13 +33,13 @@ def _init(rank, world, port):
     return parallel
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, mode="per_block"):
     parallel = _init(rank, world, port)
     g = torch.Generator().manual_seed(100 + rank)
     names = ["decoder_embed.weight", "blocks.1.attn.qkv.weight", "blocks.1.attn.rel_pos_h", "blocks.0.mlp.fc1.bias", "pos_embed"]
     shapes = [(16, 8), (12, 4), (5, 4), (7,), (1, 3, 4)]
     G = {n: torch.randn(s, generator=g) for n, s in zip(names, shapes)}
-    sync = parallel.GradSync()
+    sync = parallel.GradSync(mode=mode, bucket_bytes=600)      # coarse: 600 bytes -> the first bucket closes inside the second ready(), the rest at finish()
     sync.BIG = 40                       # (16, 8) and (12, 4) take the in-place path, the rest the flattened small-tensor message
     sync.ready(G, names[:1])            # decoder bucket first, as the engine's backward does
     sync.ready(G, names[1:3])
@@ -56,6 +56,7 @@ def _worker(rank, world, port, q):
         ref /= world
         ok &= bool(torch.allclose(G[n], ref, atol=1e-6)) and G[n].shape == torch.Size(s)
     ok &= not hasattr(sync, "set_sync")          # there is no way to skip a micro-step's exchange (replicas would diverge)
+    ok &= sync.launches == (2 if mode == "coarse" else 4)      # per_block: 2 matrices in place + 2 flattened messages; coarse: 2 coalesced launches
     # the engine's per-block arrangement: the small gradients are views of ONE pre-allocated flat buffer, exchanged in place as one
     # message (no flattening copy); the big matrix goes in place as before
     g2 = torch.Generator().manual_seed(500 + rank)
@@ -108,7 +109,7 @@ def _model_grads(P0, cfg, seeds):
     return {k: v.grad.clone() for k, v in P.items()}
 
 
-def _worker_model(rank, world, port, q):
+def _worker_model(rank, world, port, q, mode="per_block"):
     parallel = _init(rank, world, port)
     from oracle import painter_oracle as O
     torch.set_num_threads(2)
@@ -124,7 +125,7 @@ def _worker_model(rank, world, port, q):
     P0 = {k.replace("/", "."): v.detach() for k, v in holder.items()}
     ref0 = O.random_params(cfg, 50)
     same = all(torch.equal(P0[k], ref0[k]) for k in ref0)
-    sync = parallel.GradSync()
+    sync = parallel.GradSync(mode=mode, bucket_bytes=1 << 20)   # coarse: a handful of coalesced launches per micro-step for the tiny model
     sync.BIG = 4096
     names = list(P0.keys())
     acc = {n: torch.zeros_like(t) for n, t in P0.items()}
@@ -141,11 +142,11 @@ def _worker_model(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def _run(target, world=2):
+def _run(target, world=2, mode="per_block"):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=target, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port, q, mode)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=300) for _ in range(world)]
@@ -154,15 +155,21 @@ def _run(target, world=2):
     return sorted(res, key=lambda r: r[0])
 
 
-def test_gradsync_world2_gloo():
-    res = _run(_worker)
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("mode", ["per_block", "coarse"])
+def test_gradsync_world2_gloo(mode):
+    """mode "coarse" (round 5): the same gradients, collected and exchanged as a few coalesced launches -- the same averages."""
+    res = _run(_worker, mode=mode)
     assert [r for r, _ in res] == [0, 1]
     assert all(ok for _, ok in res), res
 
 
-def test_gradsync_world2_model_gradients_with_accumulation():
+@pytest.mark.parametrize("mode", ["per_block", "coarse"])
+def test_gradsync_world2_model_gradients_with_accumulation(mode):
     from oracle import painter_oracle as O
-    res = _run(_worker_model)
+    res = _run(_worker_model, mode=mode)
     assert all(same for _, same, _ in res), "broadcast_parameters did not make the replicas identical"
     g0, g1 = ({n: torch.from_numpy(a) for n, a in res[r][2].items()} for r in range(2))
     cfg = O.tiny_config()

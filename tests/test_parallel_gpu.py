@@ -131,7 +131,7 @@ def test_bench_multi_rank_branch_runs_with_two_gloo_ranks_on_one_gpu():
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "2", "--warmup", "1",
-                        "--batch", "1", "--min-seconds", "0", "--profile-steps", "0", "--no-cpu-baseline", "--no-optimizer"],
+                        "--batch", "1", "--min-seconds", "0", "--profile-steps", "0", "--no-cpu-baseline", "--no-optimizer", "--eval"],
                        capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -141,3 +141,12 @@ def test_bench_multi_rank_branch_runs_with_two_gloo_ranks_on_one_gpu():
     assert out["config"]["backend"].startswith("gloo") and out["config"]["rccl_ranks"] == 0
     assert out["value"] > 0 and abs(out["value"] - 2 * 1 * 2 / (out["ms_per_step"] * 2 / 1e3)) < 1e-2 * out["value"]
     assert out["loss"] == out["loss"] and out["build"]["lib_sha16"]
+    # round 5: the N > 1 branch times three gradient-exchange arrangements back to back (per-block GradSync, four coarse coalesced
+    # launches, the plain DDP wrapper); all three must have run, agree on the loss of their last step (same parameters, same batch, no
+    # optimizer, eval mode so that DropPath draws nothing: 1e-5 -- the arrangements only differ in HOW the same averaged gradients travel) and `value` must be the best of them
+    gv = out["extra"]["gradsync_variants"]
+    assert set(gv) == {"per_block", "coarse", "ddp"} and out["extra"]["gradsync_chosen"] in gv
+    assert gv["per_block"]["collective_launches_per_step"] > gv["coarse"]["collective_launches_per_step"] >= 1
+    assert abs(out["value"] - max(v["value"] for v in gv.values())) < 1e-6 * out["value"]
+    ls = [v["loss"] for v in gv.values()]
+    assert max(ls) - min(ls) <= 1e-5 * abs(ls[0]), ls

@@ -54,6 +54,64 @@ def test_reference_train_one_epoch_drives_the_hip_module():
     assert moved > 0.9 * len(before), moved
 
 
+@pytest.mark.parametrize("dtype,tol_loss,tol_norm", [("fp32", 1e-3, 1e-2), ("bf16", 2e-3, 3e-2)])
+def test_reference_train_one_epoch_same_losses_on_the_reference_class_and_the_hip_module(dtype, tol_loss, tol_norm):
+    """VERDICT round 4 (parity soft spot d): the unmodified engine drives BOTH models -- the reference's own Painter class (PyTorch-ROCm
+    eager under the engine's fp16 autocast) and ours (HIP kernels; autocast does not reach them) -- from the same parameters over the
+    same four batches (accum_iter 2 -> two optimizer updates, clip 3.0, the reference's NativeScalerWithGradNormCount and lr schedule,
+    plain torch.optim.AdamW).  DropPath is off in both (drop_path_rate 0: the engine puts the models in train mode and the two would
+    draw different masks), everything else is the training arrangement of engine_train.py:34-144.  Compared: the four per-iteration
+    losses, the two gradient norms the scaler reports at the update steps, the loss-scale trajectory and the averaged stats."""
+    from painter_amd import models_painter
+    eng = ref_import.load_reference_engine_train()
+    refmod = ref_import.load_reference_painter()
+    cfg = O.small_config()
+    P = O.random_params(cfg, 3)
+    batches = []
+    for k in range(4):
+        imgs, tgts, mask, valid = O.synthetic_batch(cfg, 2, 100 + k, "random")
+        batches.append((imgs, tgts, mask.reshape(2, *cfg.grid), valid))
+    args = types.SimpleNamespace(accum_iter=2, clip_grad=3.0, lr=1e-3, min_lr=1e-5, warmup_epochs=1, epochs=2, log_wandb=False)
+
+    def drive(model):
+        model.load_state_dict(P)
+        losses, norms = [], []
+        h = model.register_forward_hook(lambda mod, inp, out: losses.append(float(out[0].detach().float())))
+        scaler = eng.misc.NativeScalerWithGradNormCount()
+
+        class Rec:                                          # the engine calls loss_scaler(...) and loss_scaler.state_dict(): record the norms it returns
+            def __call__(self, *a, **k):
+                n = scaler(*a, **k)
+                if n is not None:
+                    norms.append(float(n))
+                return n
+
+            def state_dict(self):
+                return scaler.state_dict()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, betas=(0.9, 0.999), weight_decay=0.05)
+        stats = eng.train_one_epoch(model, [tuple(t.clone() for t in b) for b in batches], opt, torch.device("cuda"), 0, Rec(), log_writer=None, global_rank=0, args=args)
+        h.remove()
+        return losses, norms, stats
+
+    kw = dict(img_size=cfg.img_size, patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads,
+              drop_path_rate=0.0, window_size=14, qkv_bias=True, mlp_ratio=4, window_block_indexes=([0, 1], [3, 4]), residual_block_indexes=[],
+              use_rel_pos=True, out_feature="last_feat", decoder_embed_dim=cfg.decoder_embed_dim, loss_func="smoothl1")
+    from functools import partial
+    import torch.nn as nn
+    kw["norm_layer"] = partial(nn.LayerNorm, eps=1e-6)
+    lr_, nr_, sr_ = drive(refmod.Painter(**kw).cuda())
+    lo_, no_, so_ = drive(models_painter.Painter(compute_dtype=dtype, **kw).cuda())
+    print("train_one_epoch, reference class vs HIP module (%s): losses %s vs %s; grad norms %s vs %s; loss scale %s vs %s"
+          % (dtype, ["%.6f" % v for v in lr_], ["%.6f" % v for v in lo_], ["%.4f" % v for v in nr_], ["%.4f" % v for v in no_], sr_["loss_scale"], so_["loss_scale"]))
+    assert len(lr_) == len(lo_) == 4 and len(nr_) == len(no_) == 2
+    for a, b in zip(lr_, lo_):
+        assert abs(a - b) <= tol_loss * abs(a), (lr_, lo_)
+    for a, b in zip(nr_, no_):
+        assert abs(a - b) <= tol_norm * abs(a), (nr_, no_)
+    assert sr_["loss_scale"] == so_["loss_scale"] and abs(sr_["lr"] - so_["lr"]) < 1e-12
+    assert abs(sr_["loss"] - so_["loss"]) <= tol_loss * abs(sr_["loss"]) and abs(sr_["grad_norm"] - so_["grad_norm"]) <= tol_norm * abs(sr_["grad_norm"])
+
+
 def test_reference_run_one_image_drives_the_hip_seggpt_module():
     """seggpt_engine.run_one_image (SegGPT_inference/seggpt_engine.py:26-53), unmodified, on our SegGPT module: two prompts over one
     query (feature ensemble on), float64 host arrays in, a de-normalised [H/2, W, 3] picture out; checked against the CPU oracle."""
