@@ -4,7 +4,7 @@ into oracle/_ref/ so that they travel to the GPU box (which has no /root/referen
     python -m oracle.stage_ref            (also called by __graft_entry__.build() whenever /root/reference is present)
 
 What is staged (byte-for-byte, relative paths kept, as ONE archive oracle/_ref/reference_subset.tar.gz with a MANIFEST.json of the
-members' SHA-256 beside it; oracle/ref_import.py unpacks it into a temporary directory on first use):
+members' SHA-256 beside it; oracle/ref_import.py unpacks it on first use into a directory the process creates for itself -- mkdtemp, 0700, removed at exit):
   Painter/models_painter.py, Painter/engine_train.py, Painter/util/{misc,lr_sched,vitdet_utils,masking_generator,lr_decay}.py,
   SegGPT/SegGPT_inference/{models_seggpt.py, seggpt_engine.py, util/vitdet_utils.py}
 i.e. the model classes (the oracle behind `cpu_baseline.kind == "reference"`: Painter.forward, models_painter.py:464-472) and the two
@@ -63,30 +63,37 @@ def stage(src_root="/root/reference", verbose=True):
     return len(FILES)
 
 
+_UNPACKED = None
+
+
 def unpack():
-    """-> directory holding the staged files (unpacked once per archive content into the system's temporary directory and checked
-    against MANIFEST.json), or None when nothing is staged."""
+    """-> directory holding the staged files, or None when nothing is staged.  Unpacked ONCE PER PROCESS into a directory this process
+    created itself (tempfile.mkdtemp: mode 0700, unpredictable name, removed at exit) and checked against MANIFEST.json after writing --
+    ref_import puts the directory on sys.path, so it must not be a predictable, pre-creatable path in the shared temp dir."""
+    global _UNPACKED
+    if _UNPACKED is not None:
+        return _UNPACKED
     if not (os.path.isfile(ARCHIVE) and os.path.isfile(MANIFEST)):
         return None
+    import atexit
+    import shutil
     man = json.load(open(MANIFEST))["sha256"]
-    tag = hashlib.sha256(json.dumps(man, sort_keys=True).encode()).hexdigest()[:16]
-    root = os.path.join(tempfile.gettempdir(), "painter_amd_reference_subset_" + tag)
-
-    def good():
-        return all(os.path.isfile(os.path.join(root, rel)) and hashlib.sha256(open(os.path.join(root, rel), "rb").read()).hexdigest() == h
-                   for rel, h in man.items())
-    if not good():
-        os.makedirs(root, exist_ok=True)
-        with tarfile.open(ARCHIVE, "r:gz") as tar:
-            for m in tar.getmembers():
-                if m.name not in man or not m.isfile():
-                    raise RuntimeError("oracle/_ref: unexpected archive member %r" % m.name)
-                dst = os.path.join(root, m.name)
-                os.makedirs(os.path.dirname(dst), exist_ok=True)
-                with open(dst, "wb") as f:
-                    f.write(tar.extractfile(m).read())
-        if not good():
-            raise RuntimeError("oracle/_ref: staged files do not match MANIFEST.json")
+    root = tempfile.mkdtemp(prefix="painter_amd_reference_subset_")
+    atexit.register(shutil.rmtree, root, ignore_errors=True)
+    with tarfile.open(ARCHIVE, "r:gz") as tar:
+        for m in tar.getmembers():
+            if m.name not in man or not m.isfile():
+                raise RuntimeError("oracle/_ref: unexpected archive member %r" % m.name)
+            data = tar.extractfile(m).read()
+            if hashlib.sha256(data).hexdigest() != man[m.name]:
+                raise RuntimeError("oracle/_ref: %s does not match MANIFEST.json" % m.name)
+            dst = os.path.join(root, m.name)
+            os.makedirs(os.path.dirname(dst), exist_ok=True)
+            with open(dst, "wb") as f:
+                f.write(data)                       # the very bytes that were hashed
+    if sorted(man) != sorted(rel for rel in man if os.path.isfile(os.path.join(root, rel))):
+        raise RuntimeError("oracle/_ref: archive is missing files of MANIFEST.json")
+    _UNPACKED = root
     return root
 
 

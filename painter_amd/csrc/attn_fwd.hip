@@ -250,3 +250,9 @@ extern "C" int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* 
     if (dtype == PA_BF16) return attn_fwd_t<bf16>(qkv, ldq, rcat, out, ldo, lse, batch, L, heads, Hp, Wp, head_dim, scale, st);
     return attn_fwd_t<float>(qkv, ldq, rcat, out, ldo, lse, batch, L, heads, Hp, Wp, head_dim, scale, st);
 }
+
+extern "C" int pa_attn_launch_counts(long long* out6) {
+    if (out6 == nullptr) return (int)hipErrorInvalidValue;
+    for (int i = 0; i < 6; ++i) out6[i] = g_attn_counts[i];
+    return 0;
+}

@@ -110,6 +110,7 @@ class HotPath:
         self._pcache = {}
         self._rcache = {}
         self._side = {}
+        self._lnws = {}                # per device: ring of workspaces for the deferred LayerNorm-backward reductions (ln_workspace)
         # parameter-gradient kernels (dW = dY^T.X, bias column sums) are off the backward's critical path: they go to a second HIP
         # stream (+3.5 % at B=8; PAINTER_AMD_SIDE_STREAM=0 turns it off).  This mode exposed two things, both fixed: a cross-stream
         # allocator hazard on the gradient buckets, and SLP-packed fp32 VALU code mis-computing beside another kernel's MFMA
@@ -125,6 +126,33 @@ class HotPath:
             s = torch.cuda.Stream(device=device, priority=getattr(self, "side_priority", _SIDE_PRIORITY))
             self._side[device] = s
         return s
+
+    LN_RING = 6
+
+    def ln_workspace(self, dev, nbytes, main, side):
+        """A workspace for one deferred LayerNorm-backward reduction (ops.layernorm_bwd(defer=True, ws=...)), from a ring of LN_RING
+        buffers per device that is reused across blocks and steps -- every call used to allocate 12.6 MB that the allocator could not
+        hand out again before the side stream had caught up (up to ~0.6 GB of extra cached memory per step when it lagged).  Ordering:
+        the main-stream kernel that refills a buffer waits for the event recorded behind the side-stream reduction that last read it
+        (six launches earlier: practically never a stall).  -> (buffer, done) -- call done() after enqueueing the reduction."""
+        ring = self._lnws.setdefault(dev, {"bufs": [None] * self.LN_RING, "events": [None] * self.LN_RING, "i": 0})
+        k = ring["i"] % self.LN_RING
+        ring["i"] += 1
+        buf = ring["bufs"][k]
+        if buf is None or buf.numel() < nbytes:
+            if buf is not None and side is not None:
+                buf.record_stream(side)            # the replaced buffer may still be read by a reduction in flight
+            buf = ring["bufs"][k] = torch.empty((int(nbytes),), dtype=torch.uint8, device=dev)
+        ev = ring["events"][k]
+        if ev is not None and side is not None:
+            main.wait_event(ev)
+
+        def done():
+            if side is not None:
+                e = ring["events"][k] or torch.cuda.Event()
+                e.record(side)
+                ring["events"][k] = e
+        return buf, done
 
     # ------------------------------------------------------------------ constants / casts
     def pos_operator(self, device):
@@ -439,9 +467,11 @@ class HotPath:
             # dyT may still be read by the side stream: the attention branch's dY gets its own buffer
             dyA = torch.empty_like(dyT) if side is not None else dyT
             # (the reduction of the LayerNorm parameter-gradient partials is a parameter gradient too: side stream)
+            lnws, lndone = self.ln_workspace(dev, ops.layernorm_bwd_workspace_bytes(R, D), main, side if _SIDE_EXTRA else None)
             dx, fin = ops.layernorm_bwd(dln2, x1, mean2, rstd2, P[pre + "norm2.weight"], dres=dx, dx=dx, dxT=dyA,
-                                        rowscale=ds_a, rows_per_sample=L, gb=fl["n2"].view(2, D), dxT_colsum=fl["proj"], defer=True)
-            gb = on_side(fin, fin.buffer)
+                                        rowscale=ds_a, rows_per_sample=L, gb=fl["n2"].view(2, D), dxT_colsum=fl["proj"], defer=True, ws=lnws)
+            gb = on_side(fin)
+            lndone()
             G[pre + "attn.proj.bias"] = fl["proj"]
             del dyT
             tr("%d.dx_ln2" % i, dx); tr("%d.dyA" % i, dyA); tr("%d.gb2" % i, gb)
@@ -478,10 +508,12 @@ class HotPath:
             if dyT_next is not None:               # dyT_next is block nxt's fc2 dY: its column sum goes into block nxt's flat buffer
                 cs_next = block_flat(nxt)[1]["fc2"]
                 G["blocks.%d.mlp.fc2.bias" % nxt] = cs_next
+            lnws, lndone = self.ln_workspace(dev, ops.layernorm_bwd_workspace_bytes(R, D), main, side if _SIDE_EXTRA else None)
             dx, fin = ops.layernorm_bwd(dln1, x0, mean1, rstd1, P[pre + "norm1.weight"], dres=dx, dx=dx, dxT=dyT_next,
                                         rowscale=ds_next if dyT_next is not None else None, rows_per_sample=L, gb=fl["n1"].view(2, D),
-                                        dxT_colsum=cs_next, defer=True)
-            gb = on_side(fin, fin.buffer)
+                                        dxT_colsum=cs_next, defer=True, ws=lnws)
+            gb = on_side(fin)
+            lndone()
             G[pre + "norm1.weight"], G[pre + "norm1.bias"] = gb[0], gb[1]
             tr("%d.dx_ln1" % i, dx)
             del x0, ln1, qkv, ao, x1, ln2, gaux, act, atab
@@ -505,7 +537,14 @@ class HotPath:
             # SegGPT's two segmentation-type tokens (models_seggpt.py:415-420: added to every token of both streams of the samples of their
             # type): gradient = sum of dx over those samples' rows -- per-sample row weights (1 where the type matches) through the
             # row-scale kernel, then a column sum.  Only reached when a SegGPT module is differentiated (the reference never does).
+            # A token no sample of the batch uses gets NO gradient (None), as under the reference's autograd -- a weight-decaying optimizer
+            # then leaves it alone instead of decaying it towards zero.  (One host read of the [B] type vector at the very end of the
+            # backward.  With a gradient exchange installed every rank must take part in the same collectives, so zeros are produced
+            # there: the reference's DDP wrapper would refuse the unused parameter outright.)
+            types_present = set(S.seg_type.reshape(-1).tolist())
             for t_, nm in ((0.0, "type_token_cls"), (1.0, "type_token_ins")):
+                if t_ not in types_present and sync is None:
+                    continue
                 w = (S.seg_type.reshape(-1) == t_).to(torch.float32)
                 sel = ops.scale_cast(torch.float32, dx, torch.cat((w, w)).contiguous(), L)
                 G[nm] = ops.colsum(sel).view(1, 1, 1, D)

@@ -134,12 +134,18 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype, out=None):
     return out, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, dx=None, dxT=None, rowscale=None, rows_per_sample=1, gb=None, dxT_colsum=None, defer=False):
+def layernorm_bwd_workspace_bytes(R, D):
+    return int(lib.pa_layernorm_bwd_workspace_bytes(R, D))
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, dx=None, dxT=None, rowscale=None, rows_per_sample=1, gb=None, dxT_colsum=None, defer=False, ws=None):
     """-> dx (f32, = dres + LN'(dy)), dgamma_dbeta [2, D] (written into `gb` when given).
     dxT_colsum (f32 [D], optional, needs dxT): receives the column sums of rowscale * dx -- the bias gradient of the nn.Linear whose dY
     dxT is -- from the same pass.
     defer=True: -> (dx, finish): the parameter-gradient partial rows stay in a private buffer and `finish()` (callable once, on any stream
-    ordered behind this call) reduces them into gb / dxT_colsum and returns gb -- nothing downstream in the backward needs them."""
+    ordered behind this call) reduces them into gb / dxT_colsum and returns gb -- nothing downstream in the backward needs them.
+    ws (defer only): a caller-owned uint8 buffer of layernorm_bwd_workspace_bytes(R, D) for the partial rows (engine.HotPath.ln_workspace:
+    a ring reused across blocks and steps); a fresh tensor is allocated otherwise."""
     R, D = x.shape
     if dx is None:
         dx = torch.empty((R, D), dtype=torch.float32, device=x.device)
@@ -147,7 +153,12 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres=None, dx=None, dxT=None, rowsca
         gb = torch.empty((2, D), dtype=torch.float32, device=x.device)
     assert gb.shape == (2, D) and gb.is_contiguous() and gb.dtype == torch.float32
     nbytes = lib.pa_layernorm_bwd_workspace_bytes(R, D)
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device) if defer else workspace(nbytes, x.device)
+    if defer:
+        if ws is None:
+            ws = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+        assert ws.dtype == torch.uint8 and ws.numel() >= nbytes and ws.is_contiguous()
+    else:
+        ws = workspace(nbytes, x.device)
     if dxT_colsum is not None:
         assert dxT is not None and dxT_colsum.shape == (D,) and dxT_colsum.dtype == torch.float32 and dxT_colsum.is_contiguous()
     check(lib.pa_layernorm_bwd(code(dy.dtype), p(dy), dy.stride(0), p(x), x.stride(0), p(mean), p(rstd), p(gamma),
