@@ -799,11 +799,16 @@ int64_t attn3_table_bytes(int Bn, int L, int H, int Hp, int Wp) {
     if (!attn3_ok(L, Hp, Wp)) return 0;
     return (int64_t)Bn * H * (L / 32) * a3::ttile_bytes(Hp);
 }
-static int a3_xcd_map_on() {      // bit 0: XCD-contiguous head order (PA_ATTN_XCD=0 turns it off); bit 1: light workgroups last (PA_ATTN_LIGHT_LAST=0)
+// bit 0: XCD-contiguous head order (PA_ATTN_XCD=0 turns it off); bit 1: light workgroups (the 13th of every head: one live wave of four)
+// dispatched last -- OFF by default since round 5 (PA_ATTN_LIGHT_LAST=1 / pa_debug_set(8, 2) turn it on): interleaved A/B on the whole
+// training step 53.33 vs 53.41 ms (profiles/r05_ab_light_workgroups_last.log: inside the noise), while the light workgroups, run last,
+// find their head's K / V evicted from the XCD's L2: +50 MB per launch of fabric reads, forward and backward.
+// A change that adds bytes and buys nothing does not stay.
+static int a3_xcd_map_on() {
     static const int v = [] {
         const char* e = getenv("PA_ATTN_XCD");
         const char* l = getenv("PA_ATTN_LIGHT_LAST");
-        return ((e ? atoi(e) : 1) ? 1 : 0) | ((l ? atoi(l) : 1) ? 2 : 0);
+        return ((e ? atoi(e) : 1) ? 1 : 0) | ((l ? atoi(l) : 0) ? 2 : 0);
     }();
     if (g_attn_light_last == 1) return v & 1;
     if (g_attn_light_last == 2) return v | 2;

@@ -119,7 +119,7 @@ DEVI float wave_max(float v) {
 inline int g_relpos_splits = 0;
 // pa_debug_set(7, v): 0 = default (fused rel-pos table gradient in the generation-3 dQ kernel unless PA_ATTN3_FUSE_RELPOS=0), 1 = off, 2 = on
 inline int g_attn3_fuse = 0;
-// pa_debug_set(8, v): 0 = default (light attention workgroups dispatched last unless PA_ATTN_LIGHT_LAST=0), 1 = off, 2 = on
+// pa_debug_set(8, v): 0 = default (light attention workgroups NOT dispatched last unless PA_ATTN_LIGHT_LAST=1; round 5), 1 = off, 2 = on
 inline int g_attn_light_last = 0;
 
 // host-side launch counters of the attention entry points, by kernel family: [0..2] pa_attn_fwd on the generic (attn_fwd.hip) /

@@ -10,9 +10,10 @@
 //     channels; the 9 taps' weights stream through an 8 KB double buffer; 144 MFMA 32x32x16 per wave; 2 workgroups per CU.
 //     MFMA orientation A = weights (i = output channel), B = pixels (j): a lane owns one pixel and 32 of its channels, which is
 //     what the fused LayerNorm2D / GELU / 1x1-conv epilogue wants.
-//   wgrad: persistent workgroups (2 per CU), tile = 2 rows x 64 pixels; wave = (output-channel half, input-channel half), 9 tap
-//     accumulators; the contraction runs over pixels, so both operands are read with the transposing LDS read; the next
-//     tile's global loads are in flight under the current tile's 72 MFMAs; per-workgroup fp32 slabs, reduced in fixed order.
+//   wgrad: persistent workgroups (2 per CU) that walk down 64-pixel column strips in 2-row steps (ring of four halo rows in LDS: every
+//     input byte is fetched once); wave = (output-channel half, input-channel half), 9 tap accumulators; the contraction runs over
+//     pixels, so both operands are read with the transposing LDS read; the next step's global loads are in flight under the current
+//     step's 72 MFMAs; per-workgroup fp32 slabs, reduced in fixed order.
 #pragma once
 #include "common.h"
 #include <type_traits>
@@ -151,6 +152,17 @@ static inline bool ok(int Bn, int Hi, int Wi) {
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
+// Round 5 rewrite.  The round-1 kernel loaded a tile, stored it to LDS and only then multiplied (load -> barrier -> store -> barrier -> 72
+// MFMAs, nothing in flight under the MFMAs: matrix pipe busy 0.12, waves waiting 0.83 of their cycles, 784 us for 237 GFLOP) and fetched
+// every input row twice (a 2-row tile has a 4-row halo; vertically adjacent tiles ran on different workgroups): 1.23 GB per launch for
+// 0.82 GB of operands.  Now:
+//   * a workgroup walks DOWN the image: its tiles are consecutive 2-row steps of one 64-pixel column strip (linear tile index =
+//     strip-major), the four halo rows live in a ring of four LDS row slots, and a step only fetches the two new rows (a fresh four-row
+//     load at the workgroup's first tile and whenever the walk enters a new strip) -- every input byte is read once;
+//   * the next tile's global loads are issued right after the current tile's registers have been stored to LDS and stay in flight under
+//     the current tile's 72 MFMAs (register-staged: the loads land in the registers the stores have just released).
+// Halo row r (0..3) of the tile in ring phase p (0 / 1, flips every step, 0 after a fresh load) lives in slot (2 p + r) & 3; the step code
+// is instantiated for both phases so that every LDS offset stays an immediate.
 static inline int wgrad_groups(int ntiles) { return ntiles < 512 ? ntiles : 512; }
 
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, float* __restrict__ slab,
@@ -159,42 +171,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
     const int coh = wave & 1, cih = wave >> 1;
     const int ntx = Wi / TW, nty = Hi / WTH;
-    constexpr int HC = TW + 2, NXC = (WTH + 2) * HC * 8, NXL = (NXC + 255) / 256, NYL = WTH * TW * 8 / 256;
+    constexpr int HC = TW + 2, ROWC = HC * 8;                       // 16-byte chunks per halo row
+    constexpr int NXL = (2 * ROWC + 255) / 256, NYL = WTH * TW * 8 / 256;
 
-    uint4 xr[NXL], yr[NYL];
-    auto load_tile = [&](int tile) {
-        int t = tile;
-        const int bx = t % ntx;
-        t /= ntx;
-        const int by = t % nty, b = t / nty;
-        const int x0 = bx * TW, y0 = by * WTH;
+    // two halo rows (rbase = 0: the upper pair, only at a fresh start; 2: the pair every step fetches) of tile `tile` -> registers
+    // (straight-line: every lane loads from a clamped, valid address and a select zeroes what lies outside the image or past the last
+    // chunk -- with a branch per element hipcc kept the loads' control flow and ~200 spilled registers alive across the MFMAs)
+    auto load_rows = [&](uint4 (&r)[NXL], int tile, int rbase) {
+        const int strip = tile / nty, ty = tile - strip * nty;
+        const int b = strip / ntx, bx = strip - b * ntx;
+        const int x0 = bx * TW, y0 = ty * WTH;
         const bf16* img = x + (size_t)b * Hi * Wi * 64;
 #pragma unroll
         for (int i = 0; i < NXL; ++i) {
+            const int idx = min(tid + 256 * i, 2 * ROWC - 1);
+            const int pix = idx >> 3, ch = idx & 7, rr = pix / HC, c = pix - rr * HC;
+            const int gy = y0 - 1 + rbase + rr, gx = x0 - 1 + c;
+            const bool in = gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+            const int cy = min(max(gy, 0), Hi - 1), cx = min(max(gx, 0), Wi - 1);
+            const uint4 v = *reinterpret_cast<const uint4*>(img + ((size_t)cy * Wi + cx) * 64 + ch * 8);
+            r[i] = in ? v : zero4();
+        }
+    };
+    // registers -> LDS: halo row rbase + rr goes to ring slot (2 * phase + rbase + rr) & 3
+    auto store_rows = [&](const uint4 (&r)[NXL], int rbase, int phase) {
+#pragma unroll
+        for (int i = 0; i < NXL; ++i) {
             const int idx = tid + 256 * i;
-            xr[i] = zero4();
-            if (idx < NXC) {
-                const int pix = idx >> 3, ch = idx & 7, r = pix / HC, c = pix - r * HC;
-                const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-                if (gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) xr[i] = *reinterpret_cast<const uint4*>(img + ((size_t)gy * Wi + gx) * 64 + ch * 8);
+            if (idx < 2 * ROWC) {
+                const int pix = idx >> 3, ch = idx & 7, rr = pix / HC, c = pix - rr * HC;
+                const int slot = (2 * phase + rbase + rr) & 3;
+                *reinterpret_cast<uint4*>(smem + xbyte(slot * HS + c, ch)) = r[i];
             }
         }
-        const bf16* dimg = dy + (((size_t)b * Hi + y0) * Wi + x0) * 64;
+    };
+    uint4 xr[NXL], yr[NYL];
+    auto load_dy = [&](int tile) {
+        const int strip = tile / nty, ty = tile - strip * nty;
+        const int b = strip / ntx, bx = strip - b * ntx;
+        const bf16* dimg = dy + (((size_t)b * Hi + ty * WTH) * Wi + bx * TW) * 64;
 #pragma unroll
         for (int i = 0; i < NYL; ++i) {
             const int idx = tid + 256 * i, pix = idx >> 3, ch = idx & 7, r = pix >> 6, c = pix & 63;
             yr[i] = *reinterpret_cast<const uint4*>(dimg + ((size_t)r * Wi + c) * 64 + ch * 8);
         }
     };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < NXL; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < NXC) {
-                const int pix = idx >> 3, ch = idx & 7, r = pix / HC, c = pix - r * HC;
-                *reinterpret_cast<uint4*>(smem + xbyte(r * HS + c, ch)) = xr[i];
-            }
-        }
+    auto store_dy = [&]() {
 #pragma unroll
         for (int i = 0; i < NYL; ++i) {
             const int idx = tid + 256 * i, pix = idx >> 3, ch = idx & 7;
@@ -202,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __res
         }
     };
 
-    // transposed-fragment addresses for 16-pixel step 0 of a row (steps / rows / tap rows are immediates)
+    // transposed-fragment addresses for 16-pixel step 0 of a row (steps / rows / ring slots are immediates)
     const int i16 = lane & 15, half = (lane >> 4) & 1;
     int ya[2], xa[3][2];
 #pragma unroll
@@ -223,25 +245,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    auto step = [&](auto rr_c, auto m_c) {
-        constexpr int rr = decltype(rr_c)::value, m = decltype(m_c)::value;
+    auto step = [&](auto ph_c, auto rr_c, auto m_c) {
+        constexpr int ph = decltype(ph_c)::value, rr = decltype(rr_c)::value, m = decltype(m_c)::value;
         constexpr int yo = (rr * TW + 16 * m) * 128;
         const bf16x8 a = tr_frag(smem + ya[0] + yo, smem + ya[1] + yo);
         auto one = [&](auto tap_c) {
             constexpr int tap = decltype(tap_c)::value;
-            constexpr int xo = ((rr + tap / 3) * HS + 16 * m) * 128;
+            constexpr int slot = (2 * ph + rr + tap / 3) & 3;
+            constexpr int xo = (slot * HS + 16 * m) * 128;
             const bf16x8 bb = tr_frag(smem + xa[tap % 3][0] + xo, smem + xa[tap % 3][1] + xo);
             acc[tap] = mfma(a, bb, acc[tap]);
         };
-        one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{}); one(IC<4>{}); one(IC<5>{}); one(IC<6>{}); one(IC<7>{}); one(IC<8>{});
+        // (fences: left alone, hipcc hoists the fragment reads of several steps above the first MFMA and spills ~400 registers around them;
+        // one step's ten fragments in flight are plenty to cover the LDS latency under nine MFMAs)
+        one(IC<0>{}); one(IC<1>{}); one(IC<2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        one(IC<3>{}); one(IC<4>{}); one(IC<5>{});
+        __builtin_amdgcn_sched_barrier(0);
+        one(IC<6>{}); one(IC<7>{}); one(IC<8>{});
+        __builtin_amdgcn_sched_barrier(0);
     };
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        load_tile(tile);
-        __syncthreads();                       // every wave has finished reading the previous tile
-        store_tile();
+    auto compute = [&](auto ph_c) {
+        step(ph_c, IC<0>{}, IC<0>{}); step(ph_c, IC<0>{}, IC<1>{}); step(ph_c, IC<0>{}, IC<2>{}); step(ph_c, IC<0>{}, IC<3>{});
+        step(ph_c, IC<1>{}, IC<0>{}); step(ph_c, IC<1>{}, IC<1>{}); step(ph_c, IC<1>{}, IC<2>{}); step(ph_c, IC<1>{}, IC<3>{});
+    };
+    // this workgroup's run of the linear tile order (balanced to within one tile).  Every step's LOWER row pair and dY rows are
+    // prefetched one tile ahead (xr / yr); the UPPER pair of a fresh start (the run's first tile, a new strip) is fetched on the spot --
+    // an exposed round trip once or twice per workgroup, in exchange for 20 fewer staging registers across the MFMAs.
+    const int t0 = (int)((int64_t)ntiles * blockIdx.x / gridDim.x), t1 = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
+    int phase = 0;
+    if (t0 < t1) { load_rows(xr, t0, 2); load_dy(t0); }
+    for (int tile = t0; tile < t1; ++tile) {
+        const bool fresh = tile == t0 || tile % nty == 0;
+        __syncthreads();                       // every wave has finished reading the slots / the dY image this tile overwrites
+        if (fresh) {
+            phase = 0;
+            uint4 xq[NXL];
+            load_rows(xq, tile, 0);
+            store_rows(xq, 0, 0);
+        }
+        store_rows(xr, 2, phase);
+        store_dy();
+        if (tile + 1 < t1) { load_rows(xr, tile + 1, 2); load_dy(tile + 1); }      // travel under this tile's MFMAs
         __syncthreads();
-        step(IC<0>{}, IC<0>{}); step(IC<0>{}, IC<1>{}); step(IC<0>{}, IC<2>{}); step(IC<0>{}, IC<3>{});
-        step(IC<1>{}, IC<0>{}); step(IC<1>{}, IC<1>{}); step(IC<1>{}, IC<2>{}); step(IC<1>{}, IC<3>{});
+        if (phase == 0) compute(IC<0>{});
+        else compute(IC<1>{});
+        phase ^= 1;                            // (reset to 0 above when the next tile starts fresh)
     }
     float* o = slab + (size_t)blockIdx.x * W_SLAB;
     const int ci = cih * 32 + (lane & 31);

@@ -513,7 +513,6 @@ def test_attn3_fused_relpos_gradient_vs_dG_gemm(B, H, Hp, Wp):
     out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
     res = {}
     try:
-        assert lib.pa_debug_set(9, 1) == 0                  # generation 3 for every tile: the two routes then share the key loop bit for bit
         for mode in (2, 1, 2):
             assert lib.pa_debug_set(7, mode) == 0
             nb = lib.pa_attn_bwd_relpos_partials_bytes(PA_BF16, B, L, H, Hp, Wp, 64)
@@ -526,7 +525,6 @@ def test_attn3_fused_relpos_gradient_vs_dG_gemm(B, H, Hp, Wp):
             res[mode] = (dqkv.clone(), drcat.clone())
     finally:
         lib.pa_debug_set(7, 0)
-        lib.pa_debug_set(9, 0)
     assert torch.equal(res[1][0], res[2][0])
     assert relerr(res[2][1], res[1][1]) < 1e-5, relerr(res[2][1], res[1][1])
     q64 = qkv.double().clone().requires_grad_(True)

@@ -35,21 +35,23 @@ def build(cfg, seed, dtype, train=False):
 
 
 # Gates on the bf16 build's gradients against the unmodified reference's fp32 gradients (the tests print what they measure, pytest -s).
-#  * every tensor except the rel-pos tables: every 997th element, max|a - b| / max|b| per tensor.  Measured on MI355X over rounds 3-4:
-#    <= 2.2e-2 at ViT-L (B = 1 and B = 8); gate 6e-2 (a dropped head or a mis-indexed tile moves a sampled tensor by >= 1/16).  The
-#    head_dim-80 small model has short tensors (few samples, larger spread: 4.0e-2 .. 6.3e-2 measured): gate 1e-1 there.
-#  * rel_pos_h / rel_pos_w ([111, 64] / [55, 64]): 8 / 4 samples at stride 997 say little, so since round 4 the fixtures carry these
-#    gradients WHOLE (grad_full/<name>) and the gate is the relative Frobenius error over the full tensor, 5e-2.  They are the noisiest
-#    gradients of the model for a structural reason, not a loose kernel: d rel_pos = sum over samples, heads and queries of class sums of
-#    dS = P o (dP - Delta), whose rows sum to zero -- the class sums are differences of nearly cancelling terms, and a bf16 build carries a
-#    2^-9 relative rounding on every P, dS and bias-table entry (the kernel-level error against fp64 on bf16-exact operands is 5e-3:
-#    tests/test_kernels_gpu.py).  The rounding of the per-query bias gradient dG that round 3 suspected is NOT the cause: with the
-#    gradient contracted inside the dQ kernel from fp32 partials (round 4) the error is unchanged to three digits.  The sampled rel-max
-#    stays as a coarse second check at 2e-1 (measured 8.4e-2 .. 1.3e-1 on 4-8 samples per tensor).
-BF16_SAMPLE_GATE = 6.0e-2          # every tensor except the rel-pos tables, ViT-L fixtures
-BF16_SAMPLE_GATE_SHORT = 1.0e-1    # the head_dim-80 small model
-BF16_RELPOS_FRO_GATE = 5.0e-2      # rel-pos tables: relative Frobenius error over the full tensor
-BF16_RELPOS_GATE = 2.0e-1          # rel-pos tables: sampled rel-max (coarse)
+# Since round 5 they are tied to a MEASUREMENT OF THE REFERENCE ITSELF (tools/grad_yardstick.py on the GPU box,
+# profiles/r05_reference_bf16_gradient_yardstick.json): the unmodified reference Painter at ViT-L, B = 1, under
+# torch.autocast(bfloat16) -- the arrangement of engine_train.py:65-75 -- against its own fp32 run, same parameters and batch as
+# tests/golden/painter_vitl.npz, same metrics as below:
+#                                                        reference bf16 autocast      HIP bf16 build (same process)
+#    sampled rel-max, every tensor but the rel-pos tables      1.95e-2                     2.26e-2        (medians 9.8e-3 / 8.3e-3)
+#    sampled rel-max, rel-pos tables                           1.28e-1                     1.07e-1
+#    rel-pos tables, full-tensor relative Frobenius            4.17e-2                     3.71e-2        (medians 3.9e-2 / 3.3e-2)
+# Gates = 1.5 x the reference's own deviation (3.0e-2, 1.9e-1); the Frobenius gate stays at the tighter 5e-2 of round 4 (1.5 x would be
+# 6.3e-2).  So the error of the rel-pos table gradients -- the noisiest tensors of the model: class sums of dS = P o (dP - Delta), whose rows
+# sum to zero, under a 2^-9 rounding of every P, dS and bias-table entry -- is a property of bf16 arithmetic on this model that the
+# reference shows to the same degree, not a loose kernel.  The head_dim-80 small model has short tensors (few samples per tensor, larger
+# spread: 4.0e-2 .. 6.3e-2 measured) and no yardstick of its own: 1e-1 there.
+BF16_SAMPLE_GATE = 3.0e-2          # every tensor except the rel-pos tables, ViT-L fixtures: 1.5 x the reference's own 1.95e-2
+BF16_SAMPLE_GATE_SHORT = 1.0e-1    # the head_dim-80 small models
+BF16_RELPOS_FRO_GATE = 5.0e-2      # rel-pos tables: relative Frobenius error over the full tensor (reference's own: 4.17e-2)
+BF16_RELPOS_GATE = 1.9e-1          # rel-pos tables: sampled rel-max, 1.5 x the reference's own 1.28e-1
 
 
 def _check_bf16_samples(fx, case, m, tag, rtol_norm=1e-1, atol_dot=5e-2, small_rtol=1e-1, sample_gate=BF16_SAMPLE_GATE):

@@ -40,15 +40,13 @@ def main():
         rcatT = ops.relpos_pack_t(rel_h, rel_w, Hp, Wp, T)
         fl = 4.0 * B * H * L * L * 64
         nrp = rcat.shape[0]
-        cases = (("gen2", 2, 1, 1, 1), ("gen3 round-3 arrangement", 0, 1, 1, 1), ("gen3 fused + light-last", 0, 2, 2, 1),
-                 ("gen4 64-row dQ (experiment)", 0, 2, 2, 2))
+        cases = (("gen2", 2, 1, 1), ("gen3 round-3 arrangement", 0, 1, 1), ("gen3 fused", 0, 2, 1), ("gen3 fused + light-last", 0, 2, 2))
         res = {c[0]: [] for c in cases}
         for _ in range(rounds):
-            for name, gen_, fuse, light, g4 in cases:
+            for name, gen_, fuse, light in cases:
                 lib.pa_attn_set_generation(gen_)
                 lib.pa_debug_set(7, fuse)
                 lib.pa_debug_set(8, light)
-                lib.pa_debug_set(9, g4)
                 out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
                 tf = timeit(lambda: ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True))
                 tb = timeit(lambda: ops.attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=tables))
@@ -61,8 +59,7 @@ def main():
         lib.pa_attn_set_generation(0)
         lib.pa_debug_set(7, 0)
         lib.pa_debug_set(8, 0)
-        lib.pa_debug_set(9, 0)
-        for name, _, _, _, _ in cases:
+        for name, _, _, _ in cases:
             tf, tb, tr = (min(r[i] for r in res[name]) for i in range(3))
             print("B'=%d %-26s fwd %.3f ms (%.0f TFLOP/s)   bwd core %.3f ms (%.0f TFLOP/s algorithmic, 2.5x fwd)   bwd + rel-pos gradient %.3f ms   rounds fwd %s core %s full %s"
                   % (B, name, tf, fl / tf / 1e9, tb, 2.5 * fl / tb / 1e9, tr, ["%.3f" % r[0] for r in res[name]], ["%.3f" % r[1] for r in res[name]],
