@@ -45,7 +45,8 @@ int pa_abi_version(void);
  * of the weight-gradient GEMM (0 = 256, the whole chip; 64 when the weight gradients run on a side stream); 4 = row-tile height of the un-split bf16
  * GEMMs: 0 by rule (224 rows where that fills the last round of workgroups better), 1 always 256, 2 224 wherever possible; 6 = K splits of the
  * rel-pos table-gradient GEMM; 7 = rel-pos table gradient inside the generation-3 dQ kernel: 0 default (on), 1 off, 2 on (tests);
- * 8 = generation-3 attention: workgroups with idle waves dispatched last: 0 default (off since round 5), 1 off, 2 on. */
+ * 8 = generation-3 attention: workgroups with idle waves dispatched last: 0 default (off since round 5), 1 off, 2 on;
+ * 9 = tests: cap on the workgroups of the conv3x3 weight-gradient kernel (0 = 512), so that small images make a workgroup walk many tiles. */
 int pa_debug_set(int which, int value);
 int pa_debug_get(int which);      /* the value last set (-1: no such knob) -- callers that change a knob temporarily restore what they found */
 

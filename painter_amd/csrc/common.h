@@ -122,6 +122,10 @@ inline int g_attn3_fuse = 0;
 // pa_debug_set(8, v): 0 = default (light attention workgroups NOT dispatched last unless PA_ATTN_LIGHT_LAST=1; round 5), 1 = off, 2 = on
 inline int g_attn_light_last = 0;
 
+// pa_debug_set(9, n): tests only -- cap on the number of workgroups of the conv3x3 weight-gradient kernel (0 = the product's 512): with a small
+// cap every workgroup walks many tiles, through both ring phases and across column-strip boundaries, at test sizes
+inline int g_conv_wgrad_groups = 0;
+
 // host-side launch counters of the attention entry points, by kernel family: [0..2] pa_attn_fwd on the generic (attn_fwd.hip) /
 // generation-2 (attn2.hip) / generation-3 (attn3.hip) kernels, [3..5] pa_attn_bwd likewise (pa_attn_launch_counts; the model-level tests
 // assert with them WHICH kernels a configuration ran on)

@@ -163,7 +163,10 @@ static inline bool ok(int Bn, int Hi, int Wi) {
 //     the current tile's 72 MFMAs (register-staged: the loads land in the registers the stores have just released).
 // Halo row r (0..3) of the tile in ring phase p (0 / 1, flips every step, 0 after a fresh load) lives in slot (2 p + r) & 3; the step code
 // is instantiated for both phases so that every LDS offset stays an immediate.
-static inline int wgrad_groups(int ntiles) { return ntiles < 512 ? ntiles : 512; }
+static inline int wgrad_groups(int ntiles) {
+    const int cap = g_conv_wgrad_groups > 0 ? g_conv_wgrad_groups : 512;      // 512 = two resident workgroups per CU; pa_debug_set(9, n): tests
+    return ntiles < cap ? ntiles : cap;
+}
 
 __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ x, float* __restrict__ slab,
                                                                int Hi, int Wi, int ntiles) {
@@ -171,56 +174,70 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __res
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 5;
     const int coh = wave & 1, cih = wave >> 1;
     const int ntx = Wi / TW, nty = Hi / WTH;
-    constexpr int HC = TW + 2, ROWC = HC * 8;                       // 16-byte chunks per halo row
-    constexpr int NXL = (2 * ROWC + 255) / 256, NYL = WTH * TW * 8 / 256;
-
-    // two halo rows (rbase = 0: the upper pair, only at a fresh start; 2: the pair every step fetches) of tile `tile` -> registers
-    // (straight-line: every lane loads from a clamped, valid address and a select zeroes what lies outside the image or past the last
-    // chunk -- with a branch per element hipcc kept the loads' control flow and ~200 spilled registers alive across the MFMAs)
-    auto load_rows = [&](uint4 (&r)[NXL], int tile, int rbase) {
+    // Staging map (chosen so that NOTHING per-chunk is worth hoisting out of the tile loop -- the first version of this kernel indexed
+    // the 66-pixel halo rows linearly, hipcc kept ~40 loop-invariant index / address registers per thread alive across the MFMAs and
+    // spilled 200 registers): thread = (pixel px0 = tid / 8, 16-byte chunk ch = tid % 8); a halo row's 64 body pixels are two chunks per
+    // thread (px0, px0 + 32), the two edge columns of a row pair are one more chunk for threads 0..31.  The XOR swizzle of the LDS image
+    // depends on pixel-column bits 1..3 only, so px0 + 32 (and the second dY row, + 64) swizzle like px0: one LDS base per thread.
+    struct Stage { uint4 v[4]; uint4 e; };
+    const int px0 = tid >> 3, ch = tid & 7;
+    const int e_rr = (tid >> 4) & 1, e_c = ((tid >> 3) & 1) ? TW + 1 : 0;        // edge chunk of threads 0..31: row of the pair, halo column 0 / 65
+    const int xlds = (1 + px0) * 128 + ((ch ^ vsw(1 + px0)) << 4);               // body pixel px0 of a halo row (column 1 + px0)
+    const int elds = e_c * 128 + ((ch ^ vsw(e_c)) << 4);
+    const int ylds = W_XB + px0 * 128 + ((ch ^ vsw(px0)) << 4);
+    auto tile_origin = [&](int tile, int& b, int& x0, int& y0) {
         const int strip = tile / nty, ty = tile - strip * nty;
-        const int b = strip / ntx, bx = strip - b * ntx;
-        const int x0 = bx * TW, y0 = ty * WTH;
-        const bf16* img = x + (size_t)b * Hi * Wi * 64;
+        b = strip / ntx;
+        x0 = (strip - b * ntx) * TW;
+        y0 = ty * WTH;
+    };
+    // two halo rows (rbase = 0: the upper pair, only at a fresh start; 2: the pair every step fetches) of tile `tile` -> registers.
+    // Straight-line: every lane loads from a clamped, valid address and a select zeroes what lies outside the image.
+    auto load_rows = [&](Stage& r, int tile, int rbase) {
+        int b, x0, y0;
+        tile_origin(tile, b, x0, y0);
+        const bf16* img = x + (size_t)b * Hi * Wi * 64 + ch * 8;
 #pragma unroll
-        for (int i = 0; i < NXL; ++i) {
-            const int idx = min(tid + 256 * i, 2 * ROWC - 1);
-            const int pix = idx >> 3, ch = idx & 7, rr = pix / HC, c = pix - rr * HC;
-            const int gy = y0 - 1 + rbase + rr, gx = x0 - 1 + c;
-            const bool in = gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
-            const int cy = min(max(gy, 0), Hi - 1), cx = min(max(gx, 0), Wi - 1);
-            const uint4 v = *reinterpret_cast<const uint4*>(img + ((size_t)cy * Wi + cx) * 64 + ch * 8);
-            r[i] = in ? v : zero4();
+        for (int rr = 0; rr < 2; ++rr) {
+            const int gy = y0 - 1 + rbase + rr;
+            const bool rowok = gy >= 0 && gy < Hi;                               // wave-uniform
+            const bf16* row = img + ((size_t)min(max(gy, 0), Hi - 1) * Wi + x0 + px0) * 64;
+            const uint4 v0 = *reinterpret_cast<const uint4*>(row), v1 = *reinterpret_cast<const uint4*>(row + 32 * 64);
+            r.v[2 * rr] = rowok ? v0 : zero4();
+            r.v[2 * rr + 1] = rowok ? v1 : zero4();
         }
+        const int gy = y0 - 1 + rbase + e_rr, gx = x0 - 1 + e_c;
+        const bool ok = gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
+        const uint4 ve = *reinterpret_cast<const uint4*>(img + ((size_t)min(max(gy, 0), Hi - 1) * Wi + min(max(gx, 0), Wi - 1)) * 64);
+        r.e = ok ? ve : zero4();
     };
     // registers -> LDS: halo row rbase + rr goes to ring slot (2 * phase + rbase + rr) & 3
-    auto store_rows = [&](const uint4 (&r)[NXL], int rbase, int phase) {
+    auto store_rows = [&](const Stage& r, int rbase, int phase) {
 #pragma unroll
-        for (int i = 0; i < NXL; ++i) {
-            const int idx = tid + 256 * i;
-            if (idx < 2 * ROWC) {
-                const int pix = idx >> 3, ch = idx & 7, rr = pix / HC, c = pix - rr * HC;
-                const int slot = (2 * phase + rbase + rr) & 3;
-                *reinterpret_cast<uint4*>(smem + xbyte(slot * HS + c, ch)) = r[i];
-            }
+        for (int rr = 0; rr < 2; ++rr) {
+            unsigned char* d = smem + ((2 * phase + rbase + rr) & 3) * (HS * 128) + xlds;
+            *reinterpret_cast<uint4*>(d) = r.v[2 * rr];
+            *reinterpret_cast<uint4*>(d + 32 * 128) = r.v[2 * rr + 1];
         }
+        if (tid < 32) *reinterpret_cast<uint4*>(smem + ((2 * phase + rbase + e_rr) & 3) * (HS * 128) + elds) = r.e;
     };
-    uint4 xr[NXL], yr[NYL];
+    Stage xr;
+    uint4 yr[4];
     auto load_dy = [&](int tile) {
-        const int strip = tile / nty, ty = tile - strip * nty;
-        const int b = strip / ntx, bx = strip - b * ntx;
-        const bf16* dimg = dy + (((size_t)b * Hi + ty * WTH) * Wi + bx * TW) * 64;
+        int b, x0, y0;
+        tile_origin(tile, b, x0, y0);
+        const bf16* dimg = dy + (((size_t)b * Hi + y0) * Wi + x0 + px0) * 64 + ch * 8;
 #pragma unroll
-        for (int i = 0; i < NYL; ++i) {
-            const int idx = tid + 256 * i, pix = idx >> 3, ch = idx & 7, r = pix >> 6, c = pix & 63;
-            yr[i] = *reinterpret_cast<const uint4*>(dimg + ((size_t)r * Wi + c) * 64 + ch * 8);
+        for (int r = 0; r < 2; ++r) {
+            yr[2 * r] = *reinterpret_cast<const uint4*>(dimg + (size_t)r * Wi * 64);
+            yr[2 * r + 1] = *reinterpret_cast<const uint4*>(dimg + ((size_t)r * Wi + 32) * 64);
         }
     };
     auto store_dy = [&]() {
 #pragma unroll
-        for (int i = 0; i < NYL; ++i) {
-            const int idx = tid + 256 * i, pix = idx >> 3, ch = idx & 7;
-            *reinterpret_cast<uint4*>(smem + W_XB + xbyte(pix, ch)) = yr[i];
+        for (int r = 0; r < 2; ++r) {
+            *reinterpret_cast<uint4*>(smem + ylds + (r * 64) * 128) = yr[2 * r];
+            *reinterpret_cast<uint4*>(smem + ylds + (r * 64 + 32) * 128) = yr[2 * r + 1];
         }
     };
 
@@ -280,7 +297,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __res
         __syncthreads();                       // every wave has finished reading the slots / the dY image this tile overwrites
         if (fresh) {
             phase = 0;
-            uint4 xq[NXL];
+            Stage xq;
             load_rows(xq, tile, 0);
             store_rows(xq, 0, 0);
         }

@@ -332,87 +332,148 @@ extern "C" int pa_patchify(const float* img, float* out, int batch, int Hp, int 
 // 16 lanes x 4 channels; parameter gradients accumulate in registers and leave as one partial row per workgroup:
 // part[blk][0:64]=dgamma [64:128]=dbeta [128:320]=dW1[3][64] [320:323]=db1.
 #define TAILP 324
+// Round 5 rewrite (was 16 lanes x 4 channels per pixel, scalar fp32, an integer division per pixel: 434 us, VALU busy 1.0, for 0.86 GB of
+// traffic): 8 lanes x 8 channels per pixel = one 16-byte load / store per lane, the channel reductions take three DPP steps for eight
+// values instead of four for four, the element-wise chains run on float2 values (v_pk_fma / v_pk_mul_f32: half the issue slots; packed
+// fp32 is exact, common.h), GELU and GELU' share their transcendentals (gelu_parts2), and (sample, pixel) advance incrementally.
+// A wave = 8 pixels per iteration; the parameter-gradient accumulators are combined across the wave's 8 pixel slots with DPP / permlane
+// steps at the end (fixed order), so LDS only holds one partial row per wave.
+DEVI float oct_sum(float v) { v = quad_sum(v); v += lane_dpp<0x141>(v); return v; }          // over the 8 lanes of a pixel; every lane gets it
 template <typename T>
 __global__ __launch_bounds__(256) void tail_bwd_kernel(const float* __restrict__ dpred, const T* __restrict__ y3, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ w1, T* __restrict__ dy3,
                                                        float* __restrict__ part, int HW, int npix, float eps) {
-    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;     // 16 pixel slots per workgroup
-    const int c0 = sub * 4;
-    const float4 ga = *reinterpret_cast<const float4*>(gamma + c0), be = *reinterpret_cast<const float4*>(beta + c0);
-    const float4 wa = *reinterpret_cast<const float4*>(w1 + c0), wb = *reinterpret_cast<const float4*>(w1 + 64 + c0),
-                 wc = *reinterpret_cast<const float4*>(w1 + 128 + c0);
-    float ag[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0}, aw[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}}, ab1[3] = {0, 0, 0};
-    const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
-    const float w4[3][4] = {{wa.x, wa.y, wa.z, wa.w}, {wb.x, wb.y, wb.z, wb.w}, {wc.x, wc.y, wc.z, wc.w}};
-    for (int pix = blockIdx.x * 16 + grp; pix < npix; pix += gridDim.x * 16) {
-        const typename TT<T>::Vec4 raw = *reinterpret_cast<const typename TT<T>::Vec4*>(y3 + (size_t)pix * 64 + c0);
-        float y[4];
-        if constexpr (sizeof(T) == 2) { y[0] = bf16_lo(raw.x); y[1] = bf16_hi(raw.x); y[2] = bf16_lo(raw.y); y[3] = bf16_hi(raw.y); }
-        else { y[0] = __builtin_bit_cast(float, raw.x); y[1] = __builtin_bit_cast(float, raw.y); y[2] = __builtin_bit_cast(float, raw.z); y[3] = __builtin_bit_cast(float, raw.w); }
-        float s = (y[0] + y[1]) + (y[2] + y[3]);
-        s = row16_sum(s);
-        const float mu = s * (1.f / 64);
-        float q = 0.f;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane & 7, slot = (threadIdx.x >> 3);             // 32 pixel slots per workgroup
+    const int c0 = sub * 8;
+    f32x2_t g2[4], b2[4], w2[3][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) q += (y[e] - mu) * (y[e] - mu);
-        q = row16_sum(q);
-        const float rs = 1.f / sqrtf(q * (1.f / 64) + eps);
-        const int b = pix / HW, rem = pix % HW;
-        const float* dp = dpred + (size_t)b * 3 * HW + rem;
-        const float d0 = dp[0], d1 = dp[(size_t)HW], d2 = dp[(size_t)2 * HW];
-        float dxh[4], xh[4], m1 = 0.f, m2 = 0.f;
+    for (int k = 0; k < 4; ++k) {
+        g2[k] = (f32x2_t){gamma[c0 + 2 * k], gamma[c0 + 2 * k + 1]};
+        b2[k] = (f32x2_t){beta[c0 + 2 * k], beta[c0 + 2 * k + 1]};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            xh[e] = (y[e] - mu) * rs;
-            const float z = xh[e] * g4[e] + b4[e];
-            float a, gz;
+        for (int o = 0; o < 3; ++o) w2[o][k] = (f32x2_t){w1[o * 64 + c0 + 2 * k], w1[o * 64 + c0 + 2 * k + 1]};
+    }
+    const f32x2_t zero2 = {0.f, 0.f};
+    f32x2_t ag[4] = {zero2, zero2, zero2, zero2}, ab[4] = {zero2, zero2, zero2, zero2};
+    f32x2_t aw[3][4] = {{zero2, zero2, zero2, zero2}, {zero2, zero2, zero2, zero2}, {zero2, zero2, zero2, zero2}};
+    float ab1[3] = {0.f, 0.f, 0.f};
+    const int stride = gridDim.x * 32;
+    // Inputs travel TWO iterations ahead of their use (a ring of two register sets): with ~150 registers only 12 waves fit a CU, and one
+    // 1 KB request per wave in flight would cap the chip at ~2 TB/s; two more per wave keep ~30 KB per CU outstanding.
+    struct In { uint4 a, b; float d0, d1, d2; };
+    struct Pos { int pix, b, rem; };
+    auto advance = [&](Pos& p) {
+        p.pix += stride;
+        p.rem += stride;
+        while (p.rem >= HW) { p.rem -= HW; ++p.b; }
+    };
+    auto fetch = [&](const Pos& p) {
+        In in;
+        const int q = min(p.pix, npix - 1);                             // past the end: a valid address, the value is never used
+        const int bb = p.pix < npix ? p.b : (npix - 1) / HW, rr = p.pix < npix ? p.rem : (npix - 1) % HW;
+        in.a = *reinterpret_cast<const uint4*>(y3 + (size_t)q * 64 + c0);
+        if constexpr (sizeof(T) == 4) in.b = *reinterpret_cast<const uint4*>(y3 + (size_t)q * 64 + c0 + 4);
+        else in.b = in.a;
+        const float* dp = dpred + (size_t)bb * 3 * HW + rr;
+        in.d0 = dp[0]; in.d1 = dp[(size_t)HW]; in.d2 = dp[(size_t)2 * HW];
+        return in;
+    };
+    Pos cur, nxt;
+    cur.pix = blockIdx.x * 32 + slot;
+    cur.b = cur.pix / HW;
+    cur.rem = cur.pix - cur.b * HW;
+    nxt = cur;
+    In in0 = fetch(nxt);
+    advance(nxt);
+    In in1 = fetch(nxt);
+    advance(nxt);
+    for (; cur.pix < npix; advance(cur)) {
+        const In in = in0;
+        in0 = in1;
+        in1 = fetch(nxt);
+        advance(nxt);
+        const int pix = cur.pix;
+        f32x2_t y[4];
+        if constexpr (sizeof(T) == 2) {
+            const uint4 raw = in.a;
+            y[0] = (f32x2_t){bf16_lo(raw.x), bf16_hi(raw.x)}; y[1] = (f32x2_t){bf16_lo(raw.y), bf16_hi(raw.y)};
+            y[2] = (f32x2_t){bf16_lo(raw.z), bf16_hi(raw.z)}; y[3] = (f32x2_t){bf16_lo(raw.w), bf16_hi(raw.w)};
+        } else {
+            y[0] = (f32x2_t){__builtin_bit_cast(float, in.a.x), __builtin_bit_cast(float, in.a.y)};
+            y[1] = (f32x2_t){__builtin_bit_cast(float, in.a.z), __builtin_bit_cast(float, in.a.w)};
+            y[2] = (f32x2_t){__builtin_bit_cast(float, in.b.x), __builtin_bit_cast(float, in.b.y)};
+            y[3] = (f32x2_t){__builtin_bit_cast(float, in.b.z), __builtin_bit_cast(float, in.b.w)};
+        }
+        const float d0 = in.d0, d1 = in.d1, d2 = in.d2;
+        f32x2_t s2 = (y[0] + y[1]) + (y[2] + y[3]);
+        const float mu = oct_sum(s2[0] + s2[1]) * (1.f / 64);
+        const f32x2_t mu2 = {mu, mu};
+        f32x2_t q2 = zero2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { y[k] = y[k] - mu2; q2 = __builtin_elementwise_fma(y[k], y[k], q2); }
+        const float rs = 1.f / sqrtf(oct_sum(q2[0] + q2[1]) * (1.f / 64) + eps);
+        const f32x2_t rs2 = {rs, rs}, dd0 = {d0, d0}, dd1 = {d1, d1}, dd2 = {d2, d2};
+        f32x2_t dxh[4], m1 = zero2, m2 = zero2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x2_t xh = y[k] * rs2;
+            const f32x2_t z = __builtin_elementwise_fma(xh, g2[k], b2[k]);
+            f32x2_t a, gz;
             if constexpr (sizeof(T) == 2) {        // bf16 build: fast erf, one exp shared by gelu and gelu' (common.h)
-                float cdf, e2;
-                gelu_parts(z, cdf, e2);
-                a = z * cdf;
-                gz = fmaf(z * 0.39894228040143268f, e2, cdf);
+                gelu_both2(z[0], z[1], a, gz);
             } else {
-                a = gelu_f(z);
-                gz = gelu_grad_f(z);
+                a = (f32x2_t){gelu_f(z[0]), gelu_f(z[1])};
+                gz = (f32x2_t){gelu_grad_f(z[0]), gelu_grad_f(z[1])};
             }
-            const float da = d0 * w4[0][e] + d1 * w4[1][e] + d2 * w4[2][e];
-            const float dz = da * gz;
-            ag[e] += dz * xh[e];
-            ab[e] += dz;
-            aw[0][e] += d0 * a; aw[1][e] += d1 * a; aw[2][e] += d2 * a;
-            dxh[e] = dz * g4[e];
-            m1 += dxh[e];
-            m2 += dxh[e] * xh[e];
+            const f32x2_t da = __builtin_elementwise_fma(dd2, w2[2][k], __builtin_elementwise_fma(dd1, w2[1][k], dd0 * w2[0][k]));
+            const f32x2_t dz = da * gz;
+            ag[k] = __builtin_elementwise_fma(dz, xh, ag[k]);
+            ab[k] = ab[k] + dz;
+            aw[0][k] = __builtin_elementwise_fma(dd0, a, aw[0][k]);
+            aw[1][k] = __builtin_elementwise_fma(dd1, a, aw[1][k]);
+            aw[2][k] = __builtin_elementwise_fma(dd2, a, aw[2][k]);
+            dxh[k] = dz * g2[k];
+            m1 = m1 + dxh[k];
+            m2 = __builtin_elementwise_fma(dxh[k], xh, m2);
+            y[k] = xh;
         }
         if (sub == 0) { ab1[0] += d0; ab1[1] += d1; ab1[2] += d2; }
-        m1 = row16_sum(m1);
-        m2 = row16_sum(m2);
-        m1 *= (1.f / 64); m2 *= (1.f / 64);
-        float r[4];
+        const float m1s = oct_sum(m1[0] + m1[1]) * (1.f / 64), m2s = oct_sum(m2[0] + m2[1]) * (1.f / 64);
+        const f32x2_t mm1 = {m1s, m1s}, nm2 = {-m2s, -m2s};
+        f32x2_t r[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] = rs * (dxh[e] - m1 - xh[e] * m2);
-        *reinterpret_cast<typename TT<T>::Vec4*>(dy3 + (size_t)pix * 64 + c0) = cvt4(r[0], r[1], r[2], r[3], (T*)nullptr);
+        for (int k = 0; k < 4; ++k) r[k] = rs2 * (__builtin_elementwise_fma(y[k], nm2, dxh[k]) - mm1);
+        if constexpr (sizeof(T) == 2) {
+            *reinterpret_cast<uint4*>(dy3 + (size_t)pix * 64 + c0) = make_uint4(pack_bf16x2(r[0][0], r[0][1]), pack_bf16x2(r[1][0], r[1][1]),
+                                                                                 pack_bf16x2(r[2][0], r[2][1]), pack_bf16x2(r[3][0], r[3][1]));
+        } else {
+            *reinterpret_cast<float4*>(dy3 + (size_t)pix * 64 + c0) = make_float4(r[0][0], r[0][1], r[1][0], r[1][1]);
+            *reinterpret_cast<float4*>(dy3 + (size_t)pix * 64 + c0 + 4) = make_float4(r[2][0], r[2][1], r[3][0], r[3][1]);
+        }
     }
-    __shared__ float red[16][TAILP];
+    // the 8 lanes l, l + 8, ..., l + 56 hold the same 8 channels (other pixels): rotate-by-8 inside a row of 16 lanes, then across rows
+    auto wsum = [&](float v) { v += lane_dpp<0x128>(v); v += lane_xor16(v); v += lane_xor32(v); return v; };
+    __shared__ float red[4][TAILP];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        red[grp][c0 + e] = ag[e];
-        red[grp][64 + c0 + e] = ab[e];
-        red[grp][128 + c0 + e] = aw[0][e];
-        red[grp][192 + c0 + e] = aw[1][e];
-        red[grp][256 + c0 + e] = aw[2][e];
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float vg = wsum(ag[k][e]), vb = wsum(ab[k][e]), v0 = wsum(aw[0][k][e]), v1 = wsum(aw[1][k][e]), v2 = wsum(aw[2][k][e]);
+            if (lane < 8) {
+                const int c = c0 + 2 * k + e;
+                red[wave][c] = vg; red[wave][64 + c] = vb; red[wave][128 + c] = v0; red[wave][192 + c] = v1; red[wave][256 + c] = v2;
+            }
+        }
+    {
+        const float t0 = wsum(ab1[0]), t1 = wsum(ab1[1]), t2 = wsum(ab1[2]);      // (only the sub == 0 lanes carry values: lanes 0, 8, ..., 56)
+        if (lane == 0) { red[wave][320] = t0; red[wave][321] = t1; red[wave][322] = t2; red[wave][323] = 0.f; }
     }
-    if (sub == 0) { red[grp][320] = ab1[0]; red[grp][321] = ab1[1]; red[grp][322] = ab1[2]; red[grp][323] = 0.f; }
     __syncthreads();
-    for (int i = threadIdx.x; i < TAILP; i += 256) {
-        float s = 0.f;
-#pragma unroll
-        for (int gq = 0; gq < 16; ++gq) s += red[gq][i];
-        part[(size_t)blockIdx.x * TAILP + i] = s;
-    }
+    for (int i = threadIdx.x; i < TAILP; i += 256) part[(size_t)blockIdx.x * TAILP + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
 static int tail_bwd_blocks(int npix) {
-    int b = (npix + 15) / 16;
+    int b = (npix + 31) / 32;
     return b > 2048 ? 2048 : b;
 }
 extern "C" int64_t pa_decoder_tail_bwd_workspace_bytes(int batch, int Hi, int Wi) { return (int64_t)tail_bwd_blocks(batch * Hi * Wi) * TAILP * sizeof(float); }

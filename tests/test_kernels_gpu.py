@@ -564,7 +564,7 @@ def test_determinism_same_input_bit_identical():
     assert torch.equal(c, d)
 
 
-@pytest.mark.parametrize("B,Hi,Wi", [(2, 16, 128), (1, 32, 64)])
+@pytest.mark.parametrize("B,Hi,Wi", [(2, 16, 128), (1, 32, 64), (2, 64, 192)])
 def test_conv64_bf16_tile_kernels(B, Hi, Wi):
     """Dedicated bf16 3x3 conv kernels (csrc/conv64.h; Wi % 64 == 0 takes them): fused decoder tail forward, data gradient with
     the inverse pixel shuffle, weight gradient -- against torch conv2d on the same bf16-rounded operands
@@ -600,6 +600,48 @@ def test_conv64_bf16_tile_kernels(B, Hi, Wi):
     dw_ref = torch.nn.grad.conv2d_weight(xn, (64, 64, 3, 3), dyn, padding=1)
     assert relerr(dw, dw_ref) < 1e-4
     assert torch.equal(dw, ops.conv3x3_wgrad(dy, x))
+    # round 5: the weight-gradient workgroups walk DOWN 64-pixel column strips in 2-row steps over a ring of four halo rows in LDS (every
+    # input row fetched once, the next step's loads in flight under the MFMAs).  At these sizes every workgroup has one tile; capping the
+    # number of workgroups makes each walk many -- both ring phases, fresh starts at strip boundaries in the middle of a run, uneven runs
+    from painter_amd._lib import lib
+    try:
+        for cap in (1, 3, 5):
+            assert lib.pa_debug_set(9, cap) == 0
+            dwc = ops.conv3x3_wgrad(dy, x)
+            assert relerr(dwc, dw_ref) < 1e-4, (cap, relerr(dwc, dw_ref))
+            assert relerr(dwc, dw) < 2e-6                                 # the same products, another summation order across workgroups
+    finally:
+        lib.pa_debug_set(9, 0)
+
+
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,Hi,Wi", [(2, 16, 64), (3, 192, 128)])
+def test_decoder_tail_pointwise_backward_vs_autograd(T, B, Hi, Wi):
+    """pa_decoder_tail_bwd_pointwise (round 5 rewrite: 8 lanes x 8 channels per pixel, float2 arithmetic, inputs two iterations ahead):
+    the backward through Conv1x1(64 -> 3) . GELU . LayerNorm2D(64) (models_painter.py:328-333, util/vitdet_utils.py:204-209) against
+    torch autograd in float64 on the same (T-rounded) conv output -- dy3 and the four parameter gradients.  The larger shape makes the
+    2048 persistent workgroups take a second, partial, grid-stride iteration that crosses sample boundaries."""
+    import torch.nn.functional as F
+    y3 = gen((B, Hi, Wi, 64), 1, 1.0, T)
+    dpred = gen((B, 3, Hi, Wi), 2, 1.0)
+    gamma, beta = 1.0 + gen((64,), 4, 0.1), gen((64,), 5, 0.1)
+    w1 = gen((3, 64), 6, 0.1)
+    dy3, grads = ops.decoder_tail_bwd_pointwise(dpred, y3, gamma, beta, w1, 1e-6)
+    y = y3.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    g64, b64, w64 = (t.double().clone().requires_grad_(True) for t in (gamma, beta, w1))
+    b1 = torch.zeros(3, dtype=torch.float64, device=DEV, requires_grad=True)
+    u = y.mean(1, keepdim=True)
+    v = (y - u).pow(2).mean(1, keepdim=True)
+    z = (y - u) / torch.sqrt(v + 1e-6) * g64[None, :, None, None] + b64[None, :, None, None]
+    pred = F.conv2d(F.gelu(z), w64[:, :, None, None], b1)
+    pred.backward(dpred.double())
+    tol = 2e-5 if T == torch.float32 else 1e-2
+    e = {"dy3": relerr(dy3.float().permute(0, 3, 1, 2), y.grad), "dgamma": relerr(grads[0:64], g64.grad), "dbeta": relerr(grads[64:128], b64.grad),
+         "dw1": relerr(grads[128:320].reshape(3, 64), w64.grad), "db1": relerr(grads[320:323], b1.grad)}
+    print("decoder tail backward %s %s:" % (T, (B, Hi, Wi)), {k: "%.2e" % v_ for k, v_ in e.items()})
+    assert e["dy3"] < tol and max(e["dgamma"], e["dbeta"], e["dw1"], e["db1"]) < (2e-5 if T == torch.float32 else 2e-4), e
+    dy3b, gradsb = ops.decoder_tail_bwd_pointwise(dpred, y3, gamma, beta, w1, 1e-6)
+    assert torch.equal(dy3, dy3b) and torch.equal(grads, gradsb)           # fixed reduction order: bit-stable
 
 
 def test_layernorm_bwd_bitstable_beside_concurrent_mfma_kernels():
