@@ -162,7 +162,7 @@ static inline bool ok(int Bn, int Hi, int Wi) {
 //   * the next tile's global loads are issued right after the current tile's registers have been stored to LDS and stay in flight under
 //     the current tile's 72 MFMAs (register-staged: the loads land in the registers the stores have just released).
 // Halo row r (0..3) of the tile in ring phase p (0 / 1, flips every step, 0 after a fresh load) lives in slot (2 p + r) & 3; the step code
-// is instantiated for both phases so that every LDS offset stays an immediate.
+// reaches the slots through four wave-uniform offsets (ONE copy of the MFMA body: see below).
 static inline int wgrad_groups(int ntiles) {
     const int cap = g_conv_wgrad_groups > 0 ? g_conv_wgrad_groups : 512;      // 512 = two resident workgroups per CU; pa_debug_set(9, n): tests
     return ntiles < cap ? ntiles : cap;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __res
     // spilled 200 registers): thread = (pixel px0 = tid / 8, 16-byte chunk ch = tid % 8); a halo row's 64 body pixels are two chunks per
     // thread (px0, px0 + 32), the two edge columns of a row pair are one more chunk for threads 0..31.  The XOR swizzle of the LDS image
     // depends on pixel-column bits 1..3 only, so px0 + 32 (and the second dY row, + 64) swizzle like px0: one LDS base per thread.
-    struct Stage { uint4 v[4]; uint4 e; };
+    // (staged chunks as a plain array -- [0..3] body, [4] edge: a struct of uint4 members is copied through a stack slot that SROA does not always remove)
     const int px0 = tid >> 3, ch = tid & 7;
     const int e_rr = (tid >> 4) & 1, e_c = ((tid >> 3) & 1) ? TW + 1 : 0;        // edge chunk of threads 0..31: row of the pair, halo column 0 / 65
     const int xlds = (1 + px0) * 128 + ((ch ^ vsw(1 + px0)) << 4);               // body pixel px0 of a halo row (column 1 + px0)
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __res
     };
     // two halo rows (rbase = 0: the upper pair, only at a fresh start; 2: the pair every step fetches) of tile `tile` -> registers.
     // Straight-line: every lane loads from a clamped, valid address and a select zeroes what lies outside the image.
-    auto load_rows = [&](Stage& r, int tile, int rbase) {
+    auto load_rows = [&](uint4 (&r)[5], int tile, int rbase) {
         int b, x0, y0;
         tile_origin(tile, b, x0, y0);
         const bf16* img = x + (size_t)b * Hi * Wi * 64 + ch * 8;
@@ -203,42 +203,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __res
             const bool rowok = gy >= 0 && gy < Hi;                               // wave-uniform
             const bf16* row = img + ((size_t)min(max(gy, 0), Hi - 1) * Wi + x0 + px0) * 64;
             const uint4 v0 = *reinterpret_cast<const uint4*>(row), v1 = *reinterpret_cast<const uint4*>(row + 32 * 64);
-            r.v[2 * rr] = rowok ? v0 : zero4();
-            r.v[2 * rr + 1] = rowok ? v1 : zero4();
+            r[2 * rr] = rowok ? v0 : zero4();
+            r[2 * rr + 1] = rowok ? v1 : zero4();
         }
         const int gy = y0 - 1 + rbase + e_rr, gx = x0 - 1 + e_c;
         const bool ok = gy >= 0 && gy < Hi && gx >= 0 && gx < Wi;
         const uint4 ve = *reinterpret_cast<const uint4*>(img + ((size_t)min(max(gy, 0), Hi - 1) * Wi + min(max(gx, 0), Wi - 1)) * 64);
-        r.e = ok ? ve : zero4();
+        r[4] = ok ? ve : zero4();
     };
     // registers -> LDS: halo row rbase + rr goes to ring slot (2 * phase + rbase + rr) & 3
-    auto store_rows = [&](const Stage& r, int rbase, int phase) {
+    auto store_rows = [&](const uint4 (&r)[5], int rbase, int phase) {
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr) {
             unsigned char* d = smem + ((2 * phase + rbase + rr) & 3) * (HS * 128) + xlds;
-            *reinterpret_cast<uint4*>(d) = r.v[2 * rr];
-            *reinterpret_cast<uint4*>(d + 32 * 128) = r.v[2 * rr + 1];
+            *reinterpret_cast<uint4*>(d) = r[2 * rr];
+            *reinterpret_cast<uint4*>(d + 32 * 128) = r[2 * rr + 1];
         }
-        if (tid < 32) *reinterpret_cast<uint4*>(smem + ((2 * phase + rbase + e_rr) & 3) * (HS * 128) + elds) = r.e;
+        if (tid < 32) *reinterpret_cast<uint4*>(smem + ((2 * phase + rbase + e_rr) & 3) * (HS * 128) + elds) = r[4];
     };
-    Stage xr;
-    uint4 yr[4];
+    uint4 xr[5];
+    uint4 yr0, yr1, yr2, yr3;          // (named: the indexed form of these four ended up in a stack slot -- stored right behind their loads)
     auto load_dy = [&](int tile) {
         int b, x0, y0;
         tile_origin(tile, b, x0, y0);
         const bf16* dimg = dy + (((size_t)b * Hi + y0) * Wi + x0 + px0) * 64 + ch * 8;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            yr[2 * r] = *reinterpret_cast<const uint4*>(dimg + (size_t)r * Wi * 64);
-            yr[2 * r + 1] = *reinterpret_cast<const uint4*>(dimg + ((size_t)r * Wi + 32) * 64);
-        }
+        yr0 = *reinterpret_cast<const uint4*>(dimg);
+        yr1 = *reinterpret_cast<const uint4*>(dimg + 32 * 64);
+        yr2 = *reinterpret_cast<const uint4*>(dimg + (size_t)Wi * 64);
+        yr3 = *reinterpret_cast<const uint4*>(dimg + ((size_t)Wi + 32) * 64);
     };
     auto store_dy = [&]() {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            *reinterpret_cast<uint4*>(smem + ylds + (r * 64) * 128) = yr[2 * r];
-            *reinterpret_cast<uint4*>(smem + ylds + (r * 64 + 32) * 128) = yr[2 * r + 1];
-        }
+        *reinterpret_cast<uint4*>(smem + ylds) = yr0;
+        *reinterpret_cast<uint4*>(smem + ylds + 32 * 128) = yr1;
+        *reinterpret_cast<uint4*>(smem + ylds + 64 * 128) = yr2;
+        *reinterpret_cast<uint4*>(smem + ylds + 96 * 128) = yr3;
     };
 
     // transposed-fragment addresses for 16-pixel step 0 of a row (steps / rows / ring slots are immediates)
@@ -262,29 +260,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    auto step = [&](auto ph_c, auto rr_c, auto m_c) {
-        constexpr int ph = decltype(ph_c)::value, rr = decltype(rr_c)::value, m = decltype(m_c)::value;
+    // ONE copy of the 72-MFMA body: the ring phase enters through four wave-uniform slot offsets (halo row r of the tile lives at
+    // srow[r]), added to the lane's fragment address per read.  (A first version instantiated the body per phase with immediate slot
+    // offsets: hipcc then gave the nine accumulators different registers in the two copies and moved all 144 of them through scratch
+    // between them -- 174 spilled registers, 921 us against the old kernel's 784.)
+    int srow[4];
+    auto step = [&](auto rr_c, auto m_c) {
+        constexpr int rr = decltype(rr_c)::value, m = decltype(m_c)::value;
         constexpr int yo = (rr * TW + 16 * m) * 128;
         const bf16x8 a = tr_frag(smem + ya[0] + yo, smem + ya[1] + yo);
         auto one = [&](auto tap_c) {
             constexpr int tap = decltype(tap_c)::value;
-            constexpr int slot = (2 * ph + rr + tap / 3) & 3;
-            constexpr int xo = (slot * HS + 16 * m) * 128;
+            const int xo = srow[rr + tap / 3] + 16 * m * 128;
             const bf16x8 bb = tr_frag(smem + xa[tap % 3][0] + xo, smem + xa[tap % 3][1] + xo);
             acc[tap] = mfma(a, bb, acc[tap]);
         };
-        // (fences: left alone, hipcc hoists the fragment reads of several steps above the first MFMA and spills ~400 registers around them;
-        // one step's ten fragments in flight are plenty to cover the LDS latency under nine MFMAs)
-        one(IC<0>{}); one(IC<1>{}); one(IC<2>{});
+        one(IC<0>{}); one(IC<1>{}); one(IC<2>{}); one(IC<3>{}); one(IC<4>{}); one(IC<5>{}); one(IC<6>{}); one(IC<7>{}); one(IC<8>{});
+        // fence per step: left alone, hipcc hoists the fragment reads of several steps above the first MFMA, takes every register that is
+        // not an accumulator for them and parks the prefetched tile (xr / yr) in scratch -- a spill store waits for its load, which undoes
+        // the prefetch.  One step's ten fragments in flight cover the LDS latency under nine MFMAs.
         __builtin_amdgcn_sched_barrier(0);
-        one(IC<3>{}); one(IC<4>{}); one(IC<5>{});
-        __builtin_amdgcn_sched_barrier(0);
-        one(IC<6>{}); one(IC<7>{}); one(IC<8>{});
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto compute = [&](auto ph_c) {
-        step(ph_c, IC<0>{}, IC<0>{}); step(ph_c, IC<0>{}, IC<1>{}); step(ph_c, IC<0>{}, IC<2>{}); step(ph_c, IC<0>{}, IC<3>{});
-        step(ph_c, IC<1>{}, IC<0>{}); step(ph_c, IC<1>{}, IC<1>{}); step(ph_c, IC<1>{}, IC<2>{}); step(ph_c, IC<1>{}, IC<3>{});
     };
     // this workgroup's run of the linear tile order (balanced to within one tile).  Every step's LOWER row pair and dY rows are
     // prefetched one tile ahead (xr / yr); the UPPER pair of a fresh start (the run's first tile, a new strip) is fetched on the spot --
@@ -292,21 +287,24 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_kernel(const bf16* __res
     const int t0 = (int)((int64_t)ntiles * blockIdx.x / gridDim.x), t1 = (int)((int64_t)ntiles * (blockIdx.x + 1) / gridDim.x);
     int phase = 0;
     if (t0 < t1) { load_rows(xr, t0, 2); load_dy(t0); }
+#pragma clang loop unroll(disable)
     for (int tile = t0; tile < t1; ++tile) {
         const bool fresh = tile == t0 || tile % nty == 0;
         __syncthreads();                       // every wave has finished reading the slots / the dY image this tile overwrites
         if (fresh) {
             phase = 0;
-            Stage xq;
+            uint4 xq[5];
             load_rows(xq, tile, 0);
             store_rows(xq, 0, 0);
         }
         store_rows(xr, 2, phase);
         store_dy();
         if (tile + 1 < t1) { load_rows(xr, tile + 1, 2); load_dy(tile + 1); }      // travel under this tile's MFMAs
+#pragma unroll
+        for (int r = 0; r < 4; ++r) srow[r] = __builtin_amdgcn_readfirstlane(((2 * phase + r) & 3) * (HS * 128));
         __syncthreads();
-        if (phase == 0) compute(IC<0>{});
-        else compute(IC<1>{});
+        step(IC<0>{}, IC<0>{}); step(IC<0>{}, IC<1>{}); step(IC<0>{}, IC<2>{}); step(IC<0>{}, IC<3>{});
+        step(IC<1>{}, IC<0>{}); step(IC<1>{}, IC<1>{}); step(IC<1>{}, IC<2>{}); step(IC<1>{}, IC<3>{});
         phase ^= 1;                            // (reset to 0 above when the next tile starts fresh)
     }
     float* o = slab + (size_t)blockIdx.x * W_SLAB;
