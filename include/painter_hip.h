@@ -37,7 +37,7 @@ enum {
 };
 
 /* Bumped whenever an entry point's argument list changes (2: `tables` in pa_attn_fwd / pa_attn_bwd; 3: `head_dim` in the attention and
- * rel-pos entry points; 4: `dxT_colsum` in pa_layernorm_bwd, `relpos_part` in pa_attn_bwd, `dx_colsum` in pa_linear_dgrad; 5: the bf16 GELU side output is gelu'(pre), pa_debug_set(9) and pa_attn4_trace are gone).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
+ * rel-pos entry points; 4: `dxT_colsum` in pa_layernorm_bwd, `relpos_part` in pa_attn_bwd, `dx_colsum` in pa_linear_dgrad; 5: the bf16 GELU side output is gelu'(pre), pa_debug_set(9) is a test knob of the conv3x3 weight gradient, pa_attn4_trace is gone, pa_attn_bwd takes `out` / `ldo`, pa_debug_get / pa_attn_launch_counts are new).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
 #define PA_ABI_VERSION 5
 int pa_abi_version(void);
 /* diagnostics only (tools/): which = 0 start-up stagger of alternate workgroup rows of the 256x256 GEMM in shader cycles,
@@ -127,16 +127,19 @@ int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void*
  *            given) of device scratch: the dQ kernel then contracts d rel_pos itself -- one fp32 [NRP, hd] partial per workgroup --
  *            dG is not written, and pa_attn_bwd_relpos_reduce() sums the partials into drcat in a fixed order (deterministic)
  *   aux    : scratch of pa_attn_bwd_aux_bytes()
- *   tables : what pa_attn_fwd wrote (NULL: the backward recomputes the bias tables itself, generation-2 kernels);
- *            the backward adds lse / delta fields to it
+ *   tables : what pa_attn_fwd wrote (NULL: the backward recomputes the bias tables itself, generation-2 kernels); since ABI 5 the forward
+ *            also writes the log-sum-exp fields of the tiles, the backward adds the Delta field
+ *   out / ldo : the forward's output O (T [batch*L, heads*hd]) or NULL.  Given with delta = NULL where pa_attn_bwd_prep_ok(): the dQ kernel
+ *            computes Delta = rowsum(dO o O) itself -- no pa_attn_bwd_delta / pa_attn_bwd_prep launch at all (ABI 5; the engine's route)
  *   rcatT  : T [hd, NRP] from pa_relpos_pack_t
  *   drcat  : f32 [NRP, hd] = [d rel_pos_h ; d rel_pos_w ; 0], overwritten */
 int pa_relpos_pack_t(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcatT, int Hp, int Wp, int head_dim,
                      hipStream_t stream);
 int pa_attn_bwd_delta(int dtype, const void* out, int64_t ldo, const void* dout, int64_t lddo, float* delta, int batch,
                       int L, int heads, int head_dim, hipStream_t stream);
-/* pa_attn_bwd_prep_ok() == 1 (28-token-wide bf16 kernels, `tables` given): pa_attn_bwd_prep computes Delta AND writes it with the
- * log-sum-exp fields into the table tiles in one pass; pa_attn_bwd is then called with delta = NULL (no pa_attn_bwd_delta launch). */
+/* pa_attn_bwd_prep_ok() == 1 (28-token-wide bf16 kernels, `tables` given): Delta can live in the table tiles.  Either pa_attn_bwd is given
+ * `out` and delta = NULL (the dQ kernel computes Delta: no extra launch), or -- the round-4 route, kept for A/B and tests -- pa_attn_bwd_prep
+ * computes Delta and writes it with the log-sum-exp fields into the tiles in one pass and pa_attn_bwd is called with delta = out = NULL. */
 int pa_attn_bwd_prep_ok(int dtype, int L, int Hp, int Wp, int head_dim);
 int pa_attn_bwd_prep(int dtype, const void* out, int64_t ldo, const void* dout, int64_t lddo, const float* lse, void* tables,
                      int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t stream);
@@ -144,7 +147,8 @@ int64_t pa_attn_bwd_aux_bytes(int batch, int L, int heads, int Hp, int Wp);
 int64_t pa_attn_bwd_relpos_partials_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp, int head_dim);
 int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, const void* rcatT, const void* dout,
                 int64_t lddo, const float* lse, const float* delta, void* dqkv, void* dG, void* relpos_part, void* aux,
-                void* tables, int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t stream);
+                void* tables, const void* out, int64_t ldo, int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale,
+                hipStream_t stream);
 int64_t pa_attn_bwd_relpos_workspace_bytes(int dtype, int batch, int L, int heads, int Hp, int Wp, int head_dim);
 int pa_attn_bwd_relpos_reduce(const void* relpos_part, float* drcat, void* workspace, int batch, int L, int heads, int Hp, int Wp,
                               int head_dim, hipStream_t stream);

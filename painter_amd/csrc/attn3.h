@@ -9,8 +9,10 @@ int attn3_fwd(const bf16* qkv, int64_t ldq, const bf16* rcat, bf16* out, int64_t
               int Hp, int Wp, float scale, hipStream_t st);
 // part != NULL (attn3_relpos_partials_bytes() of fp32 scratch): the dQ kernel contracts the rel-pos table gradient itself and writes one
 // partial per workgroup there instead of dG; attn3_relpos_reduce() sums the partials into drcat [NRP][64]
+// out / ldo (may be NULL / 0, only read when delta == NULL): the forward's output -- the dQ kernel then computes Delta itself (no prep launch)
 int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const float* delta,
-              void* tables, bf16* dqkv, bf16* dG, float* part, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st);
+              void* tables, bf16* dqkv, bf16* dG, float* part, int Bn, int L, int H, int Hp, int Wp, float scale, const bf16* out, int64_t ldo,
+              hipStream_t st);
 // Delta = rowsum(dO o O) computed and written (with -lse / scale hi + lo) straight into the table tiles: replaces pa_attn_bwd_delta + the prep
 // kernel of attn3_bwd, which then takes delta = NULL
 int attn3_bwd_prep(const bf16* out, int64_t ldo, const bf16* dout, int64_t lddo, const float* lse, void* tables, int Bn, int L, int H, int Hp,

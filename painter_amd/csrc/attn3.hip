@@ -192,7 +192,17 @@ __global__ __launch_bounds__(NT, STAGES == 1 ? 4 : 2) void fwd_kernel(const bf16
     if constexpr (STAGES == 1) { if (wave >= 2) stg = eimg + (wave - 2) * IMG; }
     if (valid) {
         const float lt = l + xor32(l);
-        if (g == 0) lse[(size_t)bh * L + q] = (m + __builtin_amdgcn_logf(lt)) * LN2_F;
+        if (g == 0) {
+            const float lse_q = (m + __builtin_amdgcn_logf(lt)) * LN2_F;
+            lse[(size_t)bh * L + q] = lse_q;
+            if (tables != nullptr) {      // -lse / scale as the bf16 hi + lo pair the dKV kernel contracts (rows Hp, Hp + 1 of the kh part): round 5,
+                unsigned char* tt = tables + ((size_t)bh * ntile + qt) * ttile_bytes(Hp);      // was a separate launch in front of the backward
+                const float x = -lse_q / scale;
+                const bf16 hi = (bf16)x;
+                *reinterpret_cast<bf16*>(tt + 2048 + Hp * 64 + ql * 2) = hi;
+                *reinterpret_cast<bf16*>(tt + 2048 + (Hp + 1) * 64 + ql * 2) = (bf16)(x - (float)hi);
+            }
+        }
         stage_rows(stg, oacc, 1.f / lt, lane);
         write_rows(stg, out + (size_t)(b * L + qt * 32) * ldo + h * ATT_HD, ldo, lane);   // same-wave LDS ops are ordered
     }
@@ -213,9 +223,14 @@ constexpr int NSMAX = 12;
 template <int MINW, bool NDL, bool TR = false, bool FUSE = false>
 __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict__ qkv, size_t ldq, const bf16* __restrict__ rcatT,
                                                           const bf16* __restrict__ dout, size_t lddo, const float* __restrict__ lse,
-                                                          const unsigned char* __restrict__ tables, bf16* __restrict__ dqkv,
+                                                          unsigned char* __restrict__ tables, bf16* __restrict__ dqkv,
                                                           bf16* __restrict__ dG, float* __restrict__ part, int L, int H, int Hp, int NRP,
-                                                          float scale, int nblk, int xcd_map, int abl, int tile0, int pslot0) {
+                                                          float scale, int nblk, int xcd_map, int abl, int tile0, int pslot0,
+                                                          const bf16* __restrict__ oatt, size_t ldo) {
+    // oatt (round 5, may be NULL): the forward's output O.  Given, this kernel computes Delta = rowsum(dO o O) of its own query rows in the
+    // prologue (each lane holds half of its row's dO: 32 products + one half-wave exchange) and writes -Delta into the table tile for the
+    // dKV launch behind it -- the prep launch that did this for every block (24 x 15 us per step on the main stream) is gone; the lse
+    // fields of the tile come from the forward.  NULL: -Delta is read from the tile (pa_attn_bwd_prep or the prep kernel wrote it).
     // tile0: first 32-query tile of every head this launch covers (0 in the product; a launch may cover the tail of every head only);
     // pslot0: first partial slot of this launch in `part`
     // abl (diagnostics, PA_ATTN3_DQ_ABL; results are WRONG with any bit set): 1 no r-space loop after the key loop, 2 no dG stores,
@@ -265,12 +280,24 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
     uint4 T0 = zero4(), T1 = zero4();
     uint4 tch[4] = {zero4(), zero4(), zero4(), zero4()};          // this lane's chunks of the kh table (Hp * 4 chunks of 16 B per wave)
     float nlse2 = 0.f, ndlt = 0.f;
-    const unsigned char* tt = tables + ((size_t)bh * ntile + qt) * ttile_bytes(Hp);
+    unsigned char* tt = tables + ((size_t)bh * ntile + qt) * ttile_bytes(Hp);
     if (valid) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             qf[s] = gfrag(base + (size_t)q * ldq, s, g);
             dof[s] = gfrag(dout + (size_t)(b * L + q) * lddo + h * ATT_HD, s, g);
+        }
+        if (oatt != nullptr) {
+            float dl = 0.f;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 of = gfrag(oatt + (size_t)(b * L + q) * ldo + h * ATT_HD, s, g);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) dl = fmaf((float)of[t], (float)dof[s][t], dl);
+            }
+            dl += xor32(dl);                                   // the other half of the row's 64 products
+            ndlt = -dl;
+            if (g == 0) *reinterpret_cast<float*>(tt + 2048 + (Hp + 2) * 64 + ql * 4) = ndlt;
         }
         T0 = *reinterpret_cast<const uint4*>(tt + ql * 64 + 16 * g);
         T1 = *reinterpret_cast<const uint4*>(tt + ql * 64 + 32 + 16 * g);
@@ -278,7 +305,7 @@ __global__ __launch_bounds__(NT, MINW) void bwd_dq_kernel(const bf16* __restrict
         for (int i = 0; i < 4; ++i)
             if (lane + 64 * i < Hp * 4) tch[i] = *reinterpret_cast<const uint4*>(tt + 2048 + (lane + 64 * i) * 16);
         nlse2 = -lse[(size_t)bh * L + q] * LOG2E_F;
-        ndlt = *reinterpret_cast<const float*>(tt + 2048 + (Hp + 2) * 64 + ql * 4);
+        if (oatt == nullptr) ndlt = *reinterpret_cast<const float*>(tt + 2048 + (Hp + 2) * 64 + ql * 4);
     }
     build_eimg(eimg, tid);
     {   // 22 KB from L2, two chunks in flight per thread (held in registers across the prologue it made the kernel spill)
@@ -883,14 +910,17 @@ int attn3_relpos_reduce(const float* part, float* drcat, float* tmp, int Bn, int
 }
 
 int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout, int64_t lddo, const float* lse, const float* delta,
-              void* tables, bf16* dqkv, bf16* dG, float* part, int Bn, int L, int H, int Hp, int Wp, float scale, hipStream_t st) {
+              void* tables, bf16* dqkv, bf16* dG, float* part, int Bn, int L, int H, int Hp, int Wp, float scale, const bf16* out, int64_t ldo,
+              hipStream_t st) {
     using namespace a3;
     const int NRP = pa_relpos_rows_padded(Hp, Wp);
     if (part != nullptr && NRP > 16 * NSMAX) return (int)hipErrorInvalidValue;
     if (part == nullptr && dG == nullptr) return (int)hipErrorInvalidValue;
     unsigned char* tb = reinterpret_cast<unsigned char*>(tables);
     int e;
-    if (delta != nullptr) {         // NULL: pa_attn_bwd_prep already filled the lse / -Delta fields of the tables
+    // delta given: the two-kernel route (pa_attn_bwd_delta + the prep kernel here).  delta NULL: with `out` the dQ kernel computes Delta itself
+    // and the forward has written the lse fields (no extra launch: the default since round 5); without `out`, pa_attn_bwd_prep has filled both
+    if (delta != nullptr) {
         const int total = Bn * H * L;
         PA_LAUNCH(prep_kernel, dim3((total + 255) / 256), dim3(256), 0, st, lse, delta, tb, L, Hp, 1.f / scale, total);
         if ((e = (int)hipGetLastError())) return e;
@@ -916,7 +946,7 @@ int attn3_bwd(const bf16* qkv, int64_t ldq, const bf16* rcatT, const bf16* dout,
         if ((e = set_smem(reinterpret_cast<const void*>(kern), fuse ? donef : (g_attn_trace ? donet : (dq_w == 3 ? done3 : done2))))) return e;
         const char* ablv = getenv("PA_ATTN3_DQ_ABL");           // diagnostics, read per launch
         PA_LAUNCH(kern, dim3(nblk * Bn * H), dim3(NT), smem, st, qkv, (size_t)ldq, rcatT, dout, (size_t)lddo, lse, tb, dqkv, dG, part, L, H,
-                  Hp, NRP, scale, nblk, a3_xcd_map_on(), ablv ? atoi(ablv) : 0, tile0, 0);
+                  Hp, NRP, scale, nblk, a3_xcd_map_on(), ablv ? atoi(ablv) : 0, tile0, 0, delta == nullptr ? out : nullptr, (size_t)ldo);
         if ((e = (int)hipGetLastError())) return e;
     }
     const int tile0_kv = 0, nblk_kv = a3_blocks(L);

@@ -531,13 +531,14 @@ extern "C" int64_t pa_attn_bwd_relpos_partials_bytes(int dtype, int batch, int L
 }
 extern "C" int pa_attn_bwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, const void* rcatT, const void* dout, int64_t lddo,
                            const float* lse, const float* delta, void* dqkv, void* dG, void* relpos_part, void* aux, void* tables,
-                           int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t st) {
+                           const void* out, int64_t ldo, int batch, int L, int heads, int Hp, int Wp, int head_dim, float scale, hipStream_t st) {
     if (L != Hp * Wp || L % 32 || Hp % 4 || Wp % 4 || (head_dim != 64 && head_dim != 80)) return (int)hipErrorInvalidValue;
     if (dtype == PA_BF16 && head_dim == ATT_HD && tables != nullptr && attn3_ok(L, Hp, Wp)) {
         if (relpos_part != nullptr && attn3_relpos_partials_bytes(batch, L, heads, Hp, Wp) == 0) return (int)hipErrorInvalidValue;
         ++g_attn_counts[5];
+        if (out != nullptr && ldo % 8) return (int)hipErrorInvalidValue;
         return attn3_bwd((const bf16*)qkv, ldq, (const bf16*)rcatT, (const bf16*)dout, lddo, lse, delta, tables, (bf16*)dqkv, (bf16*)dG,
-                         (float*)relpos_part, batch, L, heads, Hp, Wp, scale, st);
+                         (float*)relpos_part, batch, L, heads, Hp, Wp, scale, (const bf16*)out, ldo, st);
     }
     if (relpos_part != nullptr || dG == nullptr || delta == nullptr) return (int)hipErrorInvalidValue;      // only the generation-3 kernels fuse the rel-pos gradient / read Delta from the tables
     if (dtype == PA_BF16 && attn2_ok(L, Hp, Wp, head_dim)) {

@@ -221,19 +221,25 @@ def relpos_pack_t(rel_pos_h, rel_pos_w, Hp, Wp, dtype):
     return rcatT
 
 
-def attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale, tables=None):
+def attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, scale, tables=None, prep="fused"):
     """-> (dqkv T [batch*L, 3*heads*hd], dG): the data gradients and what attn_bwd_relpos() turns into the rel-pos table gradients --
     either the per-query bias gradients dG T [batch*L, heads*NRP], or (28-token-wide bf16 kernels with `tables`) the per-workgroup
     fp32 partial sums of the table gradient itself, a uint8 scratch tensor (the dQ kernel contracts them; dG never exists).
-    tables: what attn_fwd(need_tables=True) returned (the backward writes its lse / delta fields into it)."""
+    tables: what attn_fwd(need_tables=True) returned (it carries the lse fields; the backward writes its delta field into it).
+    prep (where the tables can carry Delta): "fused" = the dQ kernel computes Delta = rowsum(dO o O) itself (no extra launch: round 5),
+    "launch" = the round-4 route, one pa_attn_bwd_prep launch in front (A/B, tests)."""
     T = qkv.dtype
     dev = qkv.device
     nrp, hd = rcat.shape
     delta = None
+    o_arg = None
     if tables is not None and lib.pa_attn_bwd_prep_ok(code(T), L, Hp, Wp, hd):
-        # Delta = rowsum(dO o O) goes straight into the table tiles together with the log-sum-exp fields: one launch instead of two
-        check(lib.pa_attn_bwd_prep(code(T), p(out), out.stride(0), p(dout), dout.stride(0), p(lse), p(tables), batch, L, heads, Hp, Wp, hd,
-                                   float(scale), stream()), "pa_attn_bwd_prep")
+        if prep == "fused":
+            o_arg = out
+        else:
+            # Delta = rowsum(dO o O) goes straight into the table tiles together with the log-sum-exp fields: one launch instead of two
+            check(lib.pa_attn_bwd_prep(code(T), p(out), out.stride(0), p(dout), dout.stride(0), p(lse), p(tables), batch, L, heads, Hp, Wp, hd,
+                                       float(scale), stream()), "pa_attn_bwd_prep")
     else:
         delta = torch.empty((batch * heads, L), dtype=torch.float32, device=dev)
         check(lib.pa_attn_bwd_delta(code(T), p(out), out.stride(0), p(dout), dout.stride(0), p(delta), batch, L, heads, hd,
@@ -247,7 +253,8 @@ def attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, batch, L, heads, Hp, Wp, sca
         dG = torch.empty((batch * L, heads * nrp), dtype=T, device=dev)
     aux = workspace(lib.pa_attn_bwd_aux_bytes(batch, L, heads, Hp, Wp), dev, slot=1)
     check(lib.pa_attn_bwd(code(T), p(qkv), qkv.stride(0), p(rcat), p(rcatT), p(dout), dout.stride(0), p(lse), p(delta),
-                          p(dqkv), p(dG), p(part), p(aux), p(tables), batch, L, heads, Hp, Wp, hd, float(scale), stream()), "pa_attn_bwd")
+                          p(dqkv), p(dG), p(part), p(aux), p(tables), p(o_arg), 0 if o_arg is None else o_arg.stride(0), batch, L, heads, Hp, Wp, hd,
+                          float(scale), stream()), "pa_attn_bwd")
     return dqkv, (dG if part is None else part)
 
 

@@ -539,6 +539,27 @@ def test_attn3_fused_relpos_gradient_vs_dG_gemm(B, H, Hp, Wp):
     assert float(res[2][1][nh + nw:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("B,H,Hp,Wp", [(2, 2, 56, 28), (1, 3, 16, 28)])
+def test_attn3_delta_inside_the_dq_kernel_vs_the_prep_launch(B, H, Hp, Wp):
+    """Round 5: the forward writes the log-sum-exp fields of the table tiles and the dQ kernel computes Delta = rowsum(dO o O) of its own
+    rows (and leaves -Delta in the tiles for the dKV launch) -- the separate prep launch per block is gone.  Against the round-4 route
+    (pa_attn_bwd_prep in front) on the same inputs: another fp32 summation order of the 64 products per row, so the outputs agree to a
+    bf16 ulp here and there, not bit for bit; both are held to the fp64 reference by the tests above.  The fused route twice: bit-stable."""
+    L, qkv, rcat, rcatT, dout = _attn3_inputs(B, H, Hp, Wp)
+    out, lse, tables = ops.attn_fwd(qkv, rcat, B, L, H, Hp, Wp, 0.125, need_tables=True)
+    res = {}
+    for mode in ("fused", "launch", "fused"):
+        t = tables.clone()                                   # the forward's tiles; each route adds its own Delta field
+        dqkv, dg = ops.attn_bwd_core(qkv, rcat, rcatT, out, dout, lse, B, L, H, Hp, Wp, 0.125, tables=t, prep=mode)
+        drcat = ops.attn_bwd_relpos(dg, qkv, rcat.shape[0], B, L, H, Hp, Wp)
+        if mode in res:
+            assert torch.equal(res[mode][0], dqkv) and torch.equal(res[mode][1], drcat)
+        res[mode] = (dqkv.clone(), drcat.clone())
+    e = (relerr(res["fused"][0].float(), res["launch"][0].float()), relerr(res["fused"][1], res["launch"][1]))
+    print("Delta inside dQ vs prep launch: dqkv %.2e, d rel_pos %.2e" % e)
+    assert e[0] < 8e-3 and e[1] < 2e-3, e
+
+
 @pytest.mark.parametrize("gen_", [0])
 def test_attn3_deterministic(gen_, attn_generation):
     attn_generation(gen_)
