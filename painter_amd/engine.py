@@ -32,7 +32,7 @@ _SIDE_STREAM = os.environ.get("PAINTER_AMD_SIDE_STREAM", "1") != "0"
 _SIDE_PRIORITY = int(os.environ.get("PAINTER_AMD_SIDE_PRIORITY", "0"))
 _configured = False
 # sizing of the parameter-gradient kernels when they run on the side stream, beside the data-gradient chain (0 = stand-alone sizing)
-WGRAD_SIDE_TARGET = 128
+WGRAD_SIDE_TARGET = 96       # round 5 re-sweep on the lighter side stream (tools/step_knob_ab.py, profiles/r05_wgrad_side_target_sweep.log): 96 -> 53.08, 128 -> 53.42, 160 -> 54.09, 192 -> 54.47 ms/step
 RELPOS_SIDE_SPLITS = 8
 
 

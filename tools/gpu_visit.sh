@@ -43,7 +43,7 @@ for s in "$@"; do
     lightab)   timeout 400 python tools/step_knob_ab.py 5 6 "light last on:8=2" "light last off:8=1" > gpurun_out/lightab.log 2>&1; echo "lightab rc=$?"; tail -3 gpurun_out/lightab.log ;;
     prof1)     (cd /tmp && PAINTER_AMD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_one_stream -o one -- python $OLDPWD/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-optimizer --no-reference-gpu --no-secondary --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_one.log 2>&1); echo "prof1 done"; ls gpurun_out/prof_one_stream | head -3 ;;
     prof2)     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_two_stream -o two -- python $OLDPWD/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-optimizer --no-reference-gpu --no-secondary --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_two.log 2>&1); echo "prof2 done" ;;
-    wgsweep)   timeout 500 python tools/step_knob_ab.py 4 5 "wgrad target 96:3=96" "wgrad target 128:3=128" "wgrad target 160:3=160" "wgrad target 192:3=192" > gpurun_out/wgsweep.log 2>&1; echo "wgsweep rc=$?"; tail -5 gpurun_out/wgsweep.log ;;
+    wgsweep)   timeout 500 python tools/step_knob_ab.py 4 5 "wgrad target 48:3=48" "wgrad target 64:3=64" "wgrad target 80:3=80" "wgrad target 96:3=96" "wgrad target 112:3=112" > gpurun_out/wgsweep.log 2>&1; echo "wgsweep rc=$?"; tail -5 gpurun_out/wgsweep.log ;;
     r5quick)   timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -s -x -k "conv64 or decoder_tail or small or vitl_b8 or vit_large_b8 or gemm256" > gpurun_out/r5quick.log 2>&1; echo "r5quick rc=$?"; grep -a "passed\|failed\|rror" gpurun_out/r5quick.log | tail -5 ;;
     *)         echo "unknown section $s" ;;
   esac
