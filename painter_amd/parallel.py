@@ -86,7 +86,14 @@ class GradSync:
             return
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", FutureWarning)          # (announced deprecation of the coalesced entry point; it is what ProcessGroupNCCL batches)
-            fut = dist.all_reduce_coalesced(ts, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+            try:
+                fut = dist.all_reduce_coalesced(ts, op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+            except (RuntimeError, ValueError):
+                if not avg:
+                    raise
+                # a backend build whose coalesced path refuses AVG (argument check at call time, nothing has been enqueued): SUM + scale
+                post = 1.0 / self.world_size
+                fut = dist.all_reduce_coalesced(ts, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._pending.append((fut, ts, post))
 
     def ready(self, G, names, flat=None):
