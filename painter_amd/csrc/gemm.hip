@@ -481,8 +481,8 @@ static int wgrad_fast_splits(int M, int N, int K) {
     static const int env_target = [] { const char* v = getenv("PA_WGRAD_WGS"); return v ? atoi(v) : 0; }();
     int target = env_target > 0 ? env_target : (g256::g_dbg[3] > 0 ? g256::g_dbg[3] : 256);
     if (target < 16) target = 16;
-    int s = (target + tiles / 2) / tiles;
-    if (s < 1) s = 1;
+    int s = (target + 3 * tiles / 4) / tiles;          // (rounds up from x.25: ViT-H/14's 75-tile qkv gradient gets 2 splits = 150 workgroups at target 96, not 75 long ones;
+    if (s < 1) s = 1;                                   //  every ViT-L shape -- 16 / 48 / 64 tiles -- keeps the split count it had with round-half-up)
     const int ktiles = M / 64;
     if (s > ktiles / 4) s = ktiles / 4 > 0 ? ktiles / 4 : 1;
     return g256::splits_used(M, s);
