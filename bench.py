@@ -120,7 +120,7 @@ class KernelTimer:
     NAMES = {
         "gemm256_fwd": "g256::gemm256_kernel<false,false,*> (nn.Linear forward: qkv, proj, fc1+GELU, fc2, decoder_embed)",
         "gemm256_dgrad": "g256::gemm256_kernel<false,true,*> (nn.Linear data gradient dX = dY.W)",
-        "gemm256_wgrad": "g256::gemm256_kernel<true,true,Epi4Slab> (weight gradient dW = dY^T.X; its split-K slabs are summed by the block's one batched reduction launch since round 5, outside this bracket)",
+        "gemm256_wgrad": "g256::gemm256_kernel<true,true,Epi4Slab> + slab_reduce (weight gradient dW = dY^T.X)",
         "attention_fwd": "a3::fwd_kernel (fused attention forward, rel-pos bias on the matrix pipe; head_dim 80: a2::fwd_kernel<1,1,80>)",
         "attention_bwd": "a3::bwd_dq_kernel (rel-pos table gradient contracted inside) + a3::bwd_dkv_kernel + prep_delta (fused attention backward; head_dim 80: a2::bwd_dq_kernel<2,2,80,WP32> + a2::bwd_dkv_kernel<2,80> + delta)",
     }

@@ -37,7 +37,7 @@ enum {
 };
 
 /* Bumped whenever an entry point's argument list changes (2: `tables` in pa_attn_fwd / pa_attn_bwd; 3: `head_dim` in the attention and
- * rel-pos entry points; 4: `dxT_colsum` in pa_layernorm_bwd, `relpos_part` in pa_attn_bwd, `dx_colsum` in pa_linear_dgrad; 5: the bf16 GELU side output is gelu'(pre), pa_debug_set(9) is a test knob of the conv3x3 weight gradient, pa_attn4_trace is gone, pa_attn_bwd takes `out` / `ldo`, pa_debug_get / pa_attn_launch_counts / pa_reduce_batch_* are new).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
+ * rel-pos entry points; 4: `dxT_colsum` in pa_layernorm_bwd, `relpos_part` in pa_attn_bwd, `dx_colsum` in pa_linear_dgrad; 5: the bf16 GELU side output is gelu'(pre), pa_debug_set(9) is a test knob of the conv3x3 weight gradient, pa_attn4_trace is gone, pa_attn_bwd takes `out` / `ldo`, pa_debug_get / pa_attn_launch_counts are new).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
 #define PA_ABI_VERSION 5
 int pa_abi_version(void);
 /* diagnostics only (tools/): which = 0 start-up stagger of alternate workgroup rows of the 256x256 GEMM in shader cycles,
@@ -46,7 +46,8 @@ int pa_abi_version(void);
  * GEMMs: 0 by rule (224 rows where that fills the last round of workgroups better), 1 always 256, 2 224 wherever possible; 6 = K splits of the
  * rel-pos table-gradient GEMM; 7 = rel-pos table gradient inside the generation-3 dQ kernel: 0 default (on), 1 off, 2 on (tests);
  * 8 = generation-3 attention: workgroups with idle waves dispatched last: 0 default (off since round 5), 1 off, 2 on;
- * 9 = tests: cap on the workgroups of the conv3x3 weight-gradient kernel (0 = 512), so that small images make a workgroup walk many tiles. */
+ * 9 = tests: cap on the workgroups of the conv3x3 weight-gradient kernel (0 = 512), so that small images make a workgroup walk many tiles;
+ * 10 = LayerNorm backward (D = 1024) loads its read-once streams non-temporally: 0 default (PA_LN_NT, off), 1 off, 2 on (A/B). */
 int pa_debug_set(int which, int value);
 int pa_debug_get(int which);      /* the value last set (-1: no such knob) -- callers that change a knob temporarily restore what they found */
 
@@ -77,17 +78,6 @@ int64_t pa_colsum_workspace_bytes(int M, int N);
 int pa_colsum(int dtype, const void* x /*T [M,N]*/, int64_t ld, int M, int N, float* out /*[N]*/, void* workspace,
               hipStream_t stream);
 int pa_slab_reduce(const float* in, float* out, int64_t n, int nz, int64_t stride, int accumulate, hipStream_t stream);
-/* Batched reductions (round 5): between pa_reduce_batch_begin(stream) and pa_reduce_batch_flush(stream) the fixed-order reductions that
- * library calls issue on `stream` WHILE pa_reduce_batch_hold(1) is in effect (the tails of pa_linear_wgrad, pa_colsum, pa_layernorm_bwd_reduce,
- * pa_attn_bwd_relpos_reduce, pa_slab_reduce ...) are collected and run by the flush as ONE launch (bit-identical results: every job keeps its
- * kernel's summation order).  The caller guarantees that the inputs of queued jobs -- the `workspace` arguments of those calls -- stay
- * untouched until the flush (a private workspace per queued call) and that no queued job reads another queued job's output.  The engine
- * brackets the parameter-gradient work of every transformer block this way: ~8 reduction launches become one.  pa_reduce_batch_stats:
- * out2 = {jobs queued, launches made by flushes} since process start (tests). */
-int pa_reduce_batch_begin(hipStream_t stream);
-int pa_reduce_batch_hold(int on);
-int pa_reduce_batch_flush(hipStream_t stream);
-int pa_reduce_batch_stats(long long* out2);
 
 /* ---- nn.LayerNorm(eps=1e-6) over channels: models_painter.py:218,230 (norm1/2), :416-417 (shared tap norm) ---- */
 int pa_layernorm_fwd(int dtype, const float* x, int64_t ldx, const float* gamma, const float* beta, float eps,

@@ -295,123 +295,20 @@ __global__ __launch_bounds__(256) void slab_reduce2_kernel(const float* __restri
         *reinterpret_cast<float4*>(i < n0 ? out0 + i : out1 + (i - n0)) = t;
     }
 }
-// ---- batched reductions (round 5).  The backward of a transformer block ends ~8 small fixed-order reductions of parameter-gradient partials
-// (four weight-gradient slab sets, two LayerNorm partial-row sets, the qkv bias column sums, the second stage of the rel-pos table
-// gradient): 8 launches of 7 - 17 us each, none of them near the bandwidth such a reduction could reach.  Between pa_reduce_batch_begin(st)
-// and pa_reduce_batch_flush(st) the reductions issued on `st` while queueing is held on (pa_reduce_batch_hold) are collected instead of
-// launched, and the flush runs them all as ONE launch whose workgroups are partitioned over the jobs.  Every job keeps the summation order
-// of the kernel it would have run on (slab_reduce_wide: sequential over the slabs; slab_reduce / slab_reduce2: 16 strided lanes, then a
-// fixed-order combine), so the results are bit-identical to the unbatched path.  The CALLER guarantees that a queued job's input stays
-// untouched until the flush (private workspaces: painter_amd/ops.py) and that no queued job reads another queued job's output.
-struct RJob { const float* in; float* out0; float* out1; unsigned long long n0, n, stride; int nz, accumulate, wide, blk0; };
-constexpr int RJ_MAX = 12;
-struct RJobTable { RJob j[RJ_MAX]; int njobs; };
-__global__ __launch_bounds__(256) void multi_reduce_kernel(RJobTable t) {
-    __shared__ float4 sh[16][17];
-    int k = 0;
-#pragma unroll
-    for (int i = 1; i < RJ_MAX; ++i)
-        if (i < t.njobs && (int)blockIdx.x >= t.j[i].blk0) k = i;
-    const RJob J = t.j[k];
-    const unsigned b = blockIdx.x - J.blk0;
-    if (J.wide) {                      // = slab_reduce_wide_kernel
-        const size_t i = ((size_t)b * 256 + threadIdx.x) * 4;
-        if (i >= J.n) return;
-        float* o = i < J.n0 ? J.out0 + i : J.out1 + (i - J.n0);
-        float4 s = J.accumulate ? *reinterpret_cast<const float4*>(o) : make_float4(0, 0, 0, 0);
-#pragma unroll 4
-        for (int z = 0; z < J.nz; ++z) {
-            const float4 v = *reinterpret_cast<const float4*>(J.in + (size_t)z * J.stride + i);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-        *reinterpret_cast<float4*>(o) = s;
-        return;
-    }
-    const int cg = threadIdx.x & 15, zl = threadIdx.x >> 4;      // = slab_reduce_kernel / slab_reduce2_kernel
-    const size_t i = ((size_t)b * 16 + cg) * 4;
-    float4 s = make_float4(0, 0, 0, 0);
-    if (i < J.n) {
-#pragma unroll 4
-        for (int z = zl; z < J.nz; z += 16) {
-            const float4 v = *reinterpret_cast<const float4*>(J.in + (size_t)z * J.stride + i);
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-        }
-    }
-    sh[zl][cg] = s;
-    __syncthreads();
-    if (zl == 0 && i < J.n) {
-        float* o = i < J.n0 ? J.out0 + i : J.out1 + (i - J.n0);
-        float4 tt = J.accumulate ? *reinterpret_cast<const float4*>(o) : make_float4(0, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { const float4 v = sh[q][cg]; tt.x += v.x; tt.y += v.y; tt.z += v.z; tt.w += v.w; }
-        *reinterpret_cast<float4*>(o) = tt;
-    }
-}
-static RJobTable g_rq;
-static bool g_rbatch = false, g_rhold = false;
-static hipStream_t g_rstream = nullptr;
-static long long g_rstats[2] = {0, 0};          // jobs queued, launches made by flushes (diagnostics)
-static int reduce_flush_now(hipStream_t st) {
-    if (g_rq.njobs == 0) return 0;
-    int blocks = 0;
-    for (int i = 0; i < g_rq.njobs; ++i) {
-        RJob& J = g_rq.j[i];
-        J.blk0 = blocks;
-        blocks += (int)(J.wide ? (J.n / 4 + 255) / 256 : (J.n / 4 + 15) / 16);
-    }
-    PA_LAUNCH(multi_reduce_kernel, dim3(blocks), dim3(256), 0, st, g_rq);
-    g_rq.njobs = 0;
-    ++g_rstats[1];
-    return (int)hipGetLastError();
-}
-extern "C" int pa_reduce_batch_begin(hipStream_t st) {
-    g_rq.njobs = 0;
-    g_rbatch = true;
-    g_rhold = false;
-    g_rstream = st;
-    return 0;
-}
-extern "C" int pa_reduce_batch_hold(int on) { g_rhold = on != 0; return 0; }
-extern "C" int pa_reduce_batch_flush(hipStream_t st) {
-    const int e = (g_rbatch && st == g_rstream) ? reduce_flush_now(st) : 0;
-    g_rbatch = false;
-    g_rhold = false;
-    g_rq.njobs = 0;
-    return e;
-}
-extern "C" int pa_reduce_batch_stats(long long* out2) {
-    if (out2 == nullptr) return (int)hipErrorInvalidValue;
-    out2[0] = g_rstats[0];
-    out2[1] = g_rstats[1];
-    return 0;
-}
-// every fixed-order reduction of the library ends here: queued (see above) or launched at once on the kernel it always ran on
-static int reduce_dispatch(const float* in, float* out0, float* out1, int64_t n0, int64_t n, int nz, int64_t stride, int accumulate, bool two,
-                           hipStream_t st) {
-    const bool wide = !two && nz <= 16 && n >= (1 << 18);
-    if (g_rbatch && g_rhold && st == g_rstream) {
-        if (g_rq.njobs == RJ_MAX) { if (int e = reduce_flush_now(st)) return e; }
-        g_rq.j[g_rq.njobs++] = RJob{in, out0, out1 ? out1 : out0, (unsigned long long)n0, (unsigned long long)n, (unsigned long long)stride, nz, accumulate, wide ? 1 : 0, 0};
-        ++g_rstats[0];
-        return 0;
-    }
-    if (two)
-        PA_LAUNCH(slab_reduce2_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, in, out0, out1, (size_t)n0, (size_t)n, nz, (size_t)stride);
-    else if (wide)
-        PA_LAUNCH(slab_reduce_wide_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, in, out0, (size_t)n, nz, (size_t)stride, accumulate);
-    else
-        PA_LAUNCH(slab_reduce_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, in, out0, (size_t)n, nz, (size_t)stride, accumulate);
-    LAUNCH_CHECK();
-}
 int pa_slab_reduce2(const float* in, float* out0, float* out1, int64_t n0, int64_t n, int nz, int64_t stride, hipStream_t st) {
     if (n <= 0) return 0;
     if (n % 4 || n0 % 4 || stride % 4 || (n > n0 && out1 == nullptr)) return (int)hipErrorInvalidValue;
-    return reduce_dispatch(in, out0, out1, n0, n, nz, stride, 0, true, st);
+    PA_LAUNCH(slab_reduce2_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, in, out0, out1, (size_t)n0, (size_t)n, nz, (size_t)stride);
+    LAUNCH_CHECK();
 }
 extern "C" int pa_slab_reduce(const float* in, float* out, int64_t n, int nz, int64_t stride, int accumulate, hipStream_t st) {
     if (n <= 0) return 0;
     if (n % 4 || stride % 4) return (int)hipErrorInvalidValue;
-    return reduce_dispatch(in, out, nullptr, n, n, nz, stride, accumulate, false, st);
+    if (nz <= 16 && n >= (1 << 18))
+        PA_LAUNCH(slab_reduce_wide_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, in, out, (size_t)n, nz, (size_t)stride, accumulate);
+    else
+        PA_LAUNCH(slab_reduce_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, st, in, out, (size_t)n, nz, (size_t)stride, accumulate);
+    LAUNCH_CHECK();
 }
 
 // column sums of a [M, N] T matrix (bias gradients): stage 1 partial[chunk][N], stage 2 slab reduce (fixed order)
@@ -636,7 +533,8 @@ extern "C" int pa_linear_wgrad(int dtype, const void* dy, int64_t lddy, const vo
 
 extern "C" int pa_abi_version(void) { return PA_ABI_VERSION; }
 extern "C" int pa_debug_get(int which) {
-    if (which < 0 || which > 9) return -1;
+    if (which < 0 || which > 10) return -1;
+    if (which == 10) return g_ln_nt;
     if (which == 9) return g_conv_wgrad_groups;
     if (which == 6) return g_relpos_splits;
     if (which == 7) return g_attn3_fuse;
@@ -644,8 +542,9 @@ extern "C" int pa_debug_get(int which) {
     return g256::g_dbg[which];
 }
 extern "C" int pa_debug_set(int which, int value) {
-    if (which < 0 || which > 9) return (int)hipErrorInvalidValue;
+    if (which < 0 || which > 10) return (int)hipErrorInvalidValue;
     if (which < 8) g256::g_dbg[which] = value;
+    if (which == 10) g_ln_nt = value;
     if (which == 9) g_conv_wgrad_groups = value;
     if (which == 6) g_relpos_splits = value;
     if (which == 7) g_attn3_fuse = value;

@@ -26,7 +26,6 @@ _DBG_KEEP = os.environ.get("PAINTER_AMD_DEBUG_KEEPALIVE", "0") == "1"
 _DBG_SERIAL = os.environ.get("PAINTER_AMD_DEBUG_SERIAL", "0") == "1"
 _SIDE_EXTRA = os.environ.get("PAINTER_AMD_SIDE_EXTRA", "1") != "0"     # rel-pos and conv weight gradients on the side stream too
 _DBG_TRACE = os.environ.get("PAINTER_AMD_DEBUG_TRACE", "0") == "1"     # checksums of the backward's intermediates -> HotPath.trace
-_BATCH_REDUCE = os.environ.get("PAINTER_AMD_BATCH_REDUCE", "1") != "0"  # one batched reduction launch per transformer block (round 5); 0 = one launch per reduction
 
 
 _SIDE_STREAM = os.environ.get("PAINTER_AMD_SIDE_STREAM", "1") != "0"
@@ -343,17 +342,16 @@ class HotPath:
             -- on the side stream when enabled."""
             tag = "dec" if wname.startswith("decoder") else wname.split(".")[-2]
             if side is None or (filt is not None and tag not in filt):
-                with ops.queue_reductions():       # (their slab / partial-row reductions join the block's one batched launch when a batch is open on this stream)
-                    G[wname] = ops.linear_wgrad(dy, x)
-                    if bname not in G:             # (fc2 / proj biases: already summed by the LayerNorm backward that produced dy)
-                        G[bname] = ops.colsum(dy, out=bout)
+                G[wname] = ops.linear_wgrad(dy, x)
+                if bname not in G:                 # (fc2 / proj biases: already summed by the LayerNorm backward that produced dy)
+                    G[bname] = ops.colsum(dy, out=bout)
                 return
             if filt is not None and "nocolsum" in filt:
                 G[bname] = ops.colsum(dy, out=bout)
             if filt is not None and "nowgrad" in filt:
                 G[wname] = ops.linear_wgrad(dy, x)
             side.wait_stream(main)                 # dy (and x) are enqueued on main
-            with torch.cuda.stream(side), ops.queue_reductions():
+            with torch.cuda.stream(side):
                 if wname not in G:
                     G[wname] = ops.linear_wgrad(dy, x)
                 if bname not in G:
@@ -368,10 +366,9 @@ class HotPath:
         def on_side(fn, *inputs):
             """Run a parameter-gradient computation that nothing downstream consumes on the side stream (inputs: main-stream tensors)."""
             if side is None or not _SIDE_EXTRA:
-                with ops.queue_reductions():
-                    return fn()
+                return fn()
             side.wait_stream(main)
-            with torch.cuda.stream(side), ops.queue_reductions():
+            with torch.cuda.stream(side):
                 r = fn()
             for t in inputs:
                 t.record_stream(side)
@@ -440,16 +437,6 @@ class HotPath:
             nrp, hd = rcat.shape
             flat, fl = block_flat(i)
             del flats[i]
-            # Round 5: the ~8 small fixed-order reductions that end this block's parameter-gradient work (four weight-gradient slab sets, two
-            # LayerNorm partial-row sets, the qkv bias column sums, the rel-pos table gradient's second stage) are collected and run as ONE
-            # launch at the end of the block (ops.reduce_batch_*), on the stream that work runs on.
-            if _BATCH_REDUCE:
-                if side is not None:
-                    with torch.cuda.stream(side):
-                        ops.reduce_batch_begin()
-                else:
-                    ops.reduce_batch_begin()
-            after_flush = []                       # LayerNorm workspace-ring releases: only once the batched launch that reads them is enqueued
             # dyT = bf16(ds_m * dx) is emitted by the kernel that produces the final dx of this block's output: the tap
             # LayerNorm backward, block i+1's norm1 backward (dyT_next), or the stream-merge backward
             if i in c.taps:
@@ -484,7 +471,7 @@ class HotPath:
             dx, fin = ops.layernorm_bwd(dln2, x1, mean2, rstd2, P[pre + "norm2.weight"], dres=dx, dx=dx, dxT=dyA,
                                         rowscale=ds_a, rows_per_sample=L, gb=fl["n2"].view(2, D), dxT_colsum=fl["proj"], defer=True, ws=lnws)
             gb = on_side(fin)
-            after_flush.append(lndone)
+            lndone()
             G[pre + "attn.proj.bias"] = fl["proj"]
             del dyT
             tr("%d.dx_ln2" % i, dx); tr("%d.dyA" % i, dyA); tr("%d.gb2" % i, gb)
@@ -526,18 +513,10 @@ class HotPath:
                                         rowscale=ds_next if dyT_next is not None else None, rows_per_sample=L, gb=fl["n1"].view(2, D),
                                         dxT_colsum=cs_next, defer=True, ws=lnws)
             gb = on_side(fin)
-            after_flush.append(lndone)
+            lndone()
             G[pre + "norm1.weight"], G[pre + "norm1.bias"] = gb[0], gb[1]
             tr("%d.dx_ln1" % i, dx)
             del x0, ln1, qkv, ao, x1, ln2, gaux, act, atab
-            if _BATCH_REDUCE:
-                if side is not None:
-                    with torch.cuda.stream(side):
-                        ops.reduce_batch_flush()
-                else:
-                    ops.reduce_batch_flush()
-            for fn_ in after_flush:
-                fn_()
             ready([n for n in G if n.startswith(pre)], flat=flat)
         G["norm.weight"], G["norm.bias"] = dnorm[0], dnorm[1]
         # ---- token assembly + patch embed

@@ -23,64 +23,8 @@ def p(t):
     return 0 if t is None else t.data_ptr()
 
 
-# ---- batched reductions (include/painter_hip.h, pa_reduce_batch_*): the engine brackets the parameter-gradient work of a transformer block
-_BATCH = None          # {"stream": raw stream handle, "keep": [private workspaces alive until the flush]} while a batch is open
-_HOLD = False
-
-
-def reduce_batch_begin():
-    """Open a batch on the current stream: reductions issued on it inside `queue_reductions()` are collected until reduce_batch_flush()."""
-    global _BATCH
-    st = stream()
-    check(lib.pa_reduce_batch_begin(st), "pa_reduce_batch_begin")
-    _BATCH = {"stream": st, "keep": []}
-
-
-class queue_reductions:
-    """with ops.queue_reductions(): ... -- the fixed-order reductions at the tail of the ops called inside (linear_wgrad, colsum,
-    layernorm_bwd's deferred finish, attn_bwd_relpos) are queued instead of launched, IF a batch is open on the current stream; the ops
-    then take private workspaces (a queued job's input must stay untouched until the flush).  Only for reductions nothing reads before the
-    flush and that do not feed one another: parameter gradients."""
-
-    def __enter__(self):
-        global _HOLD
-        self.on = _BATCH is not None and _BATCH["stream"] == stream()
-        if self.on:
-            lib.pa_reduce_batch_hold(1)
-            _HOLD = True
-        return self
-
-    def __exit__(self, *exc):
-        global _HOLD
-        if self.on:
-            lib.pa_reduce_batch_hold(0)
-            _HOLD = False
-        return False
-
-
-def reduce_batch_flush():
-    """Run everything queued since reduce_batch_begin() as one launch on the current stream (which must be the batch's) and close the batch."""
-    global _BATCH, _HOLD
-    keep = _BATCH["keep"] if _BATCH is not None else None
-    _BATCH, _HOLD = None, False
-    check(lib.pa_reduce_batch_flush(stream()), "pa_reduce_batch_flush")
-    del keep               # the private workspaces go back to the allocator behind the flush launch (same stream)
-
-
-def reduce_batch_stats():
-    import ctypes
-    buf = (ctypes.c_longlong * 2)()
-    check(lib.pa_reduce_batch_stats(ctypes.addressof(buf)), "pa_reduce_batch_stats")
-    return {"jobs_queued": int(buf[0]), "flush_launches": int(buf[1])}
-
-
 def workspace(nbytes, device, slot=0):
-    """Grow-only scratch per (device, slot, current stream); safe to reuse because every user on one stream is ordered.
-    While reductions are being queued (queue_reductions() inside an open batch) every call gets a PRIVATE buffer that lives until the flush."""
-    if _HOLD and _BATCH is not None:
-        buf = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
-        _BATCH["keep"].append(buf)
-        return buf
+    """Grow-only scratch per (device, slot, current stream); safe to reuse because every user on one stream is ordered."""
     key = (device, slot, torch.cuda.current_stream(device).cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:

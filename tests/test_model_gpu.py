@@ -238,37 +238,6 @@ def test_small_seggpt_feature_ensemble_under_autograd_vs_oracle(dtype, n, merge)
         assert worst[1] < tol_g, (mg, worst)
 
 
-@pytest.mark.parametrize("dtype,side", [("bf16", True), ("bf16", False), ("fp32", True)])
-def test_batched_block_reductions_bit_identical_to_one_launch_per_reduction(dtype, side):
-    """Round 5: the ~8 small fixed-order reductions that end a transformer block's parameter-gradient work run as ONE launch per block
-    (pa_reduce_batch_*: every job keeps the summation order of the kernel it used to run on).  Every gradient must be the bits of the
-    unbatched path (PAINTER_AMD_BATCH_REDUCE=0), with the side stream and without it; and the library must really have queued
-    (reduce_batch_stats: 24 flush launches for the 24 blocks, >= 5 jobs each)."""
-    from painter_amd import engine, ops
-    cfg = O.small_config()
-    m, _ = build(cfg, 11, dtype, train=False)
-    m._hot.use_side_stream = side
-    res = {}
-    try:
-        for flag in (True, False, True):
-            engine._BATCH_REDUCE = flag
-            s0 = ops.reduce_batch_stats()
-            run_painter(m, cfg, 2, 21, "random")
-            s1 = ops.reduce_batch_stats()
-            g = [p.grad.detach().clone() for p in m.parameters()]
-            if flag:
-                assert s1["flush_launches"] - s0["flush_launches"] == cfg.depth and s1["jobs_queued"] - s0["jobs_queued"] >= 5 * cfg.depth, (s0, s1)
-            else:
-                assert s1 == s0
-            if flag in res:
-                assert all(torch.equal(a, b) for a, b in zip(res[flag], g))
-            res[flag] = g
-    finally:
-        engine._BATCH_REDUCE = True
-    bad = [n for (n, _), a, b in zip(m.named_parameters(), res[True], res[False]) if not torch.equal(a, b)]
-    assert not bad, bad[:5]
-
-
 def test_ignore_rule_and_determinism():
     cfg = O.small_config()
     m, P = build(cfg, 1, "bf16")
