@@ -46,8 +46,7 @@ int pa_abi_version(void);
  * GEMMs: 0 by rule (224 rows where that fills the last round of workgroups better), 1 always 256, 2 224 wherever possible; 6 = K splits of the
  * rel-pos table-gradient GEMM; 7 = rel-pos table gradient inside the generation-3 dQ kernel: 0 default (on), 1 off, 2 on (tests);
  * 8 = generation-3 attention: workgroups with idle waves dispatched last: 0 default (off since round 5), 1 off, 2 on;
- * 9 = tests: cap on the workgroups of the conv3x3 weight-gradient kernel (0 = 512), so that small images make a workgroup walk many tiles;
- * 10 = LayerNorm backward (D = 1024) loads its read-once streams non-temporally: 0 default (PA_LN_NT, off), 1 off, 2 on (A/B). */
+ * 9 = tests: cap on the workgroups of the conv3x3 weight-gradient kernel (0 = 512), so that small images make a workgroup walk many tiles. */
 int pa_debug_set(int which, int value);
 int pa_debug_get(int which);      /* the value last set (-1: no such knob) -- callers that change a knob temporarily restore what they found */
 

@@ -126,9 +126,6 @@ inline int g_attn_light_last = 0;
 // cap every workgroup walks many tiles, through both ring phases and across column-strip boundaries, at test sizes
 inline int g_conv_wgrad_groups = 0;
 
-// pa_debug_set(10, v): LayerNorm backward loads its read-once streams (the saved x, the incoming dy) non-temporally: 0 = default, 1 = off, 2 = on
-inline int g_ln_nt = 0;
-
 // host-side launch counters of the attention entry points, by kernel family: [0..2] pa_attn_fwd on the generic (attn_fwd.hip) /
 // generation-2 (attn2.hip) / generation-3 (attn3.hip) kernels, [3..5] pa_attn_bwd likewise (pa_attn_launch_counts; the model-level tests
 // assert with them WHICH kernels a configuration ran on)

@@ -533,8 +533,7 @@ extern "C" int pa_linear_wgrad(int dtype, const void* dy, int64_t lddy, const vo
 
 extern "C" int pa_abi_version(void) { return PA_ABI_VERSION; }
 extern "C" int pa_debug_get(int which) {
-    if (which < 0 || which > 10) return -1;
-    if (which == 10) return g_ln_nt;
+    if (which < 0 || which > 9) return -1;
     if (which == 9) return g_conv_wgrad_groups;
     if (which == 6) return g_relpos_splits;
     if (which == 7) return g_attn3_fuse;
@@ -542,9 +541,8 @@ extern "C" int pa_debug_get(int which) {
     return g256::g_dbg[which];
 }
 extern "C" int pa_debug_set(int which, int value) {
-    if (which < 0 || which > 10) return (int)hipErrorInvalidValue;
+    if (which < 0 || which > 9) return (int)hipErrorInvalidValue;
     if (which < 8) g256::g_dbg[which] = value;
-    if (which == 10) g_ln_nt = value;
     if (which == 9) g_conv_wgrad_groups = value;
     if (which == 6) g_relpos_splits = value;
     if (which == 7) g_attn3_fuse = value;

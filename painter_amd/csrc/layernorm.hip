@@ -4,7 +4,6 @@
 // HBM-bound: one wave per row, 16-byte loads, two-pass variance in registers, shuffle reductions.
 #include "common.h"
 #include "../../include/painter_hip.h"
-#include <cstdlib>
 
 template <typename T> DEVI void store4(T* p, float a, float b, float c, float d);
 template <> DEVI void store4<float>(float* p, float a, float b, float c, float d) {
@@ -18,20 +17,6 @@ DEVI float4 load4(const bf16* p) {
     const uint2 u = *reinterpret_cast<const uint2*>(p);
     return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y));
 }
-// the same for a stream that is read once and dead afterwards (the `nt` policy: do not keep the lines in L2 / the Infinity Cache)
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
-template <bool NT> DEVI float4 load4s(const float* p) {
-    if constexpr (!NT) return load4(p);
-    const f32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(p));
-    return make_float4(v[0], v[1], v[2], v[3]);
-}
-template <bool NT> DEVI float4 load4s(const bf16* p) {
-    if constexpr (!NT) return load4(p);
-    const u32x2_t u = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
-    return make_float4(bf16_lo(u[0]), bf16_hi(u[0]), bf16_lo(u[1]), bf16_hi(u[1]));
-}
-
 template <typename T, int NI>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, size_t ldx, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, T* __restrict__ y, size_t ldy,
@@ -80,7 +65,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // values dxT is rounded from) = the bias gradient of the nn.Linear whose dY this dxT is (fc2 / proj) -- it used to be a separate pass over dxT
 // (4 waves per SIMD: with the column-sum accumulators the kernel asked for 130 VGPRs = 3 waves per SIMD and ran 40 % slower, 69.6 vs 49.8 us
 // per ViT-L launch -- this HBM-bound stream needs the fourth wave to keep enough loads in flight)
-template <typename T, int NI, bool CS, bool NT = false>
+template <typename T, int NI, bool CS>
 __global__ __launch_bounds__(256, NI <= 4 ? 4 : 2) void ln_bwd_kernel(const T* __restrict__ dy, size_t lddy, const float* __restrict__ x, size_t ldx,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const float* dres, float* dx, size_t lddx,
@@ -107,8 +92,8 @@ __global__ __launch_bounds__(256, NI <= 4 ? 4 : 2) void ln_bwd_kernel(const T* _
         for (int i = 0; i < NI; ++i) {
             const int c = lane * 4 + 256 * i;
             if (c < D) {
-                d[i] = load4s<NT>(dyr + c);
-                const float4 xv = load4s<NT>(xr + c);
+                d[i] = load4(dyr + c);
+                const float4 xv = load4(xr + c);
                 xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y; ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
                 ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
@@ -211,11 +196,9 @@ static int ln_bwd_t(const T* dy, int64_t lddy, const float* x, int64_t ldx, cons
     if (cs && dxT == nullptr) return (int)hipErrorInvalidValue;
     const int np = cs ? 3 : 2;
     const size_t sm = (size_t)8 * D * sizeof(float);          // <= 64 KB for every D the kernel takes (NI <= 8: D <= 2048)
-    // PA_LN_NT / pa_debug_set(10, v): non-temporal loads of the read-once streams (x saved by the forward, dy from the GEMM in front)
-    static const int env_nt = [] { const char* v = getenv("PA_LN_NT"); return v ? atoi(v) : 0; }();
-    const bool nt = g_ln_nt == 1 ? false : (g_ln_nt == 2 ? true : env_nt != 0);
-#define LN_BWD3(NI, CS_, NT_) PA_LAUNCH((ln_bwd_kernel<T, NI, CS_, NT_>), grid, blk, sm, st, dy, (size_t)lddy, x, (size_t)ldx, mean, rstd, gamma, dres, dx, (size_t)lddx, dxT, (size_t)lddxT, rowscale, rps, ws, R, D)
-#define LN_BWD2(NI, CS_) do { if (nt && NI == 4) LN_BWD3(NI, CS_, true); else LN_BWD3(NI, CS_, false); } while (0)
+    // (round 5: non-temporal loads of the read-once streams -- x saved by the forward, dy from the GEMM in front -- measured 53.11 vs 53.25 ms
+    // per step, inside the noise: profiles/r05_ab_layernorm_bwd_nt_loads.log; not kept)
+#define LN_BWD2(NI, CS_) PA_LAUNCH((ln_bwd_kernel<T, NI, CS_>), grid, blk, sm, st, dy, (size_t)lddy, x, (size_t)ldx, mean, rstd, gamma, dres, dx, (size_t)lddx, dxT, (size_t)lddxT, rowscale, rps, ws, R, D)
 #define LN_BWD(NI) do { if (cs) LN_BWD2(NI, true); else LN_BWD2(NI, false); } while (0)
     if (ni <= 1) LN_BWD(1);
     else if (ni <= 2) LN_BWD(2);
@@ -225,7 +208,6 @@ static int ln_bwd_t(const T* dy, int64_t lddy, const float* x, int64_t ldx, cons
     else return (int)hipErrorInvalidValue;
 #undef LN_BWD
 #undef LN_BWD2
-#undef LN_BWD3
     int e = (int)hipGetLastError();
     if (e || dgamma_dbeta == nullptr) return e;        // NULL: the caller reduces the partial rows later (pa_layernorm_bwd_reduce, e.g. on another stream)
     // partial rows are [dgamma | dbeta (| colsum)]: one reduction launch writes the first 2 D sums to dgamma_dbeta and the rest to dxT_colsum

@@ -44,7 +44,6 @@ for s in "$@"; do
     prof1)     (cd /tmp && PAINTER_AMD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_one_stream -o one -- python $OLDPWD/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-optimizer --no-reference-gpu --no-secondary --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_one.log 2>&1); echo "prof1 done"; ls gpurun_out/prof_one_stream | head -3 ;;
     prof2)     (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_two_stream -o two -- python $OLDPWD/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-optimizer --no-reference-gpu --no-secondary --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_two.log 2>&1); echo "prof2 done" ;;
     wgsweep)   timeout 500 python tools/step_knob_ab.py 4 5 "wgrad target 48:3=48" "wgrad target 64:3=64" "wgrad target 80:3=80" "wgrad target 96:3=96" "wgrad target 112:3=112" > gpurun_out/wgsweep.log 2>&1; echo "wgsweep rc=$?"; tail -5 gpurun_out/wgsweep.log ;;
-    lnnt)      timeout 400 python tools/step_knob_ab.py 5 6 "LN bwd nt loads off:10=1" "LN bwd nt loads on:10=2" > gpurun_out/lnnt.log 2>&1; echo "lnnt rc=$?"; tail -3 gpurun_out/lnnt.log ;;
     pmc5)      (cd /tmp && for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
                   n=$(echo $c | cut -d' ' -f1); PAINTER_AMD_SIDE_STREAM=0 timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OLDPWD/gpurun_out/pmc_$n -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --no-reference-gpu --no-secondary --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/pmc_$n.log 2>&1; done)
                python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/roofline_traffic.json > gpurun_out/pmc_traffic.log 2>&1; echo "traffic rc=$?"
