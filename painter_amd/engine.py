@@ -28,6 +28,11 @@ _SIDE_EXTRA = os.environ.get("PAINTER_AMD_SIDE_EXTRA", "1") != "0"     # rel-pos
 _DBG_TRACE = os.environ.get("PAINTER_AMD_DEBUG_TRACE", "0") == "1"     # checksums of the backward's intermediates -> HotPath.trace
 
 
+# A/B switches of two round-5 / round-4 arrangements (tools/step_engine_ab.py toggles the module globals in one process):
+#   _ATTN_PREP   "fused": the dQ kernel computes Delta itself (no launch);  "launch": one pa_attn_bwd_prep launch per block (round 4)
+#   _FC1_COLSUM  "epilogue": fc1's bias gradient from the fc2 data-gradient GEMM's epilogue (round 4);  "separate": a column-sum pass on the side stream
+_ATTN_PREP = os.environ.get("PAINTER_AMD_ATTN_PREP", "fused")
+_FC1_COLSUM = os.environ.get("PAINTER_AMD_FC1_COLSUM", "epilogue")
 _SIDE_STREAM = os.environ.get("PAINTER_AMD_SIDE_STREAM", "1") != "0"
 _SIDE_PRIORITY = int(os.environ.get("PAINTER_AMD_SIDE_PRIORITY", "0"))
 _configured = False
@@ -457,8 +462,11 @@ class HotPath:
             param_grads(pre + "mlp.fc2.weight", pre + "mlp.fc2.bias", dyT, act, fl["fc2"])
             tr("%d.dyT" % i, dyT)
             # (the GEMM's epilogue also sums the columns of the dpre it stores: fc1's bias gradient, no separate pass over [R, 4D])
-            dpre = ops.linear_dgrad(dyT, self.w(pre + "mlp.fc2.weight", P), gelu_aux=gaux, colsum_out=fl["fc1"])
-            G[pre + "mlp.fc1.bias"] = fl["fc1"]
+            if _FC1_COLSUM == "epilogue":
+                dpre = ops.linear_dgrad(dyT, self.w(pre + "mlp.fc2.weight", P), gelu_aux=gaux, colsum_out=fl["fc1"])
+                G[pre + "mlp.fc1.bias"] = fl["fc1"]
+            else:                                  # A/B: param_grads below sums the columns of dpre on the side stream
+                dpre = ops.linear_dgrad(dyT, self.w(pre + "mlp.fc2.weight", P), gelu_aux=gaux)
             tr("%d.dpre" % i, dpre)
             param_grads(pre + "mlp.fc1.weight", pre + "mlp.fc1.bias", dpre, ln2, fl["fc1"])
             dln2 = ops.linear_dgrad(dpre, self.w(pre + "mlp.fc1.weight", P))
@@ -489,7 +497,7 @@ class HotPath:
             tr("%d.dao" % i, dao)
             del dyA
             rcatT = self.relpos(pre, P, True)
-            dqkv, dG = ops.attn_bwd_core(qkv, rcat, rcatT, ao, dao, lse, Bc, L, c.heads, c.Hp, c.Wp, c.scale, tables=atab)
+            dqkv, dG = ops.attn_bwd_core(qkv, rcat, rcatT, ao, dao, lse, Bc, L, c.heads, c.Hp, c.Wp, c.scale, tables=atab, prep=_ATTN_PREP)
             drcat = on_side(lambda: ops.attn_bwd_relpos(dG, qkv, nrp, Bc, L, c.heads, c.Hp, c.Wp, out=fl["rel"].view(nrp, hd)), dG, qkv)
             del dG
             tr("%d.dqkv" % i, dqkv)
