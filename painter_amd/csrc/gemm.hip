@@ -92,6 +92,12 @@ DEVI void store8(float* p, float4 a, float4 b) {
     *reinterpret_cast<float4*>(p) = a;
     *reinterpret_cast<float4*>(p + 4) = b;
 }
+// fp32 outputs in the split column layout (gemm256.h, epi_hi_off): columns j..j+3 and j+32..j+35, each half bounds-checked on its own
+// (N % 8 == 0 and j % 4 == 0: a half that starts inside the matrix ends inside it)
+DEVI void store44(float* p, int j, int N, float4 a, float4 b) {
+    if (j < N) *reinterpret_cast<float4*>(p) = a;
+    if (j + 32 < N) *reinterpret_cast<float4*>(p + 32) = b;
+}
 DEVI float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 DEVI float4 add4(float4 a, float4 b) {       // two v_pk_add_f32 (packed fp32 is exact: common.h, gelu_parts2)
     const f32x2_t l = (f32x2_t){a.x, a.y} + (f32x2_t){b.x, b.y}, h = (f32x2_t){a.z, a.w} + (f32x2_t){b.z, b.w};
@@ -109,15 +115,23 @@ DEVI EpiCol8 load_col8(const float* bias, int j, int N) {
     if (bias != nullptr && j < N) { c.a = load4(bias + j); c.b = load4(bias + j + 4); }
     return c;
 }
+DEVI EpiCol8 load_col44(const float* bias, int j, int N) {      // split layout: bias[j..j+3], bias[j+32..j+35]
+    EpiCol8 c{make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)};
+    if (bias != nullptr && j < N) c.a = load4(bias + j);
+    if (bias != nullptr && j + 32 < N) c.b = load4(bias + j + 32);
+    return c;
+}
 template <typename OutT> struct Epi4Bias {
     OutT* out; size_t ldo; const float* bias; int M, N;
+    static constexpr int HI_OFF = std::is_same<OutT, float>::value ? 32 : 4;
     typedef EpiCol8 Col;
     typedef EpiNone Row;
-    DEVI Col col(int j) const { return load_col8(bias, j, N); }
+    DEVI Col col(int j) const { return HI_OFF == 32 ? load_col44(bias, j, N) : load_col8(bias, j, N); }
     DEVI Row row(int, int) const { return Row{}; }
     DEVI void store(int i, int j, float4 a, float4 b, const Col& c, const Row&, int) const {
         if (i >= M || j >= N) return;
-        store8(out + (size_t)i * ldo + j, add4(a, c.a), add4(b, c.b));
+        if constexpr (std::is_same<OutT, float>::value) store44(out + (size_t)i * ldo + j, j, N, add4(a, c.a), add4(b, c.b));
+        else store8(out + (size_t)i * ldo + j, add4(a, c.a), add4(b, c.b));
     }
 };
 struct Epi4BiasGelu {       // aux (optional): gelu'(pre) as bf16, where rounds 1-4 stored pre itself (see EpiBiasGelu)
@@ -149,14 +163,15 @@ struct Epi4BiasGelu {       // aux (optional): gelu'(pre) as bf16, where rounds 
 };
 struct Epi4BiasResid {
     float* out; const float* resid; size_t ld; const float* bias; const float* rowscale; int rps; int M, N;
+    static constexpr int HI_OFF = 32;        // fp32 read-modify-write: every residual load and every store covers whole 128-byte segments
     typedef EpiCol8 Col;
     struct Row { float4 ra, rb; float s; };
-    DEVI Col col(int j) const { return load_col8(bias, j, N); }
+    DEVI Col col(int j) const { return load_col44(bias, j, N); }
     DEVI Row row(int i, int j) const {
         Row r{make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0), 1.f};
         if (i < M && j < N) {
             r.ra = load4(resid + (size_t)i * ld + j);
-            r.rb = load4(resid + (size_t)i * ld + j + 4);
+            if (j + 32 < N) r.rb = load4(resid + (size_t)i * ld + j + 32);
             if (rowscale) r.s = rowscale[i / rps];
         }
         return r;
@@ -166,8 +181,8 @@ struct Epi4BiasResid {
         const float s = r.s;
         a = add4(a, c.a);
         b = add4(b, c.b);
-        store8(out + (size_t)i * ld + j, make_float4(r.ra.x + s * a.x, r.ra.y + s * a.y, r.ra.z + s * a.z, r.ra.w + s * a.w),
-               make_float4(r.rb.x + s * b.x, r.rb.y + s * b.y, r.rb.z + s * b.z, r.rb.w + s * b.w));
+        store44(out + (size_t)i * ld + j, j, N, make_float4(r.ra.x + s * a.x, r.ra.y + s * a.y, r.ra.z + s * a.z, r.ra.w + s * a.w),
+                make_float4(r.rb.x + s * b.x, r.rb.y + s * b.y, r.rb.z + s * b.z, r.rb.w + s * b.w));
     }
 };
 struct Epi4DGelu {          // out = acc * aux, aux = the bf16 gelu'(pre) the fc1 forward epilogue saved (Epi4BiasGelu)
@@ -225,13 +240,14 @@ struct Epi4PixShuf {
 };
 struct Epi4Slab {
     float* out; size_t ldo; size_t slab; int M, N;
+    static constexpr int HI_OFF = 32;
     typedef EpiNone Col;
     typedef EpiNone Row;
     DEVI Col col(int) const { return Col{}; }
     DEVI Row row(int, int) const { return Row{}; }
     DEVI void store(int i, int j, float4 a, float4 b, const Col&, const Row&, int split) const {
         if (i >= M || j >= N) return;
-        store8(out + (size_t)split * slab + (size_t)i * ldo + j, a, b);
+        store44(out + (size_t)split * slab + (size_t)i * ldo + j, j, N, a, b);
     }
 };
 

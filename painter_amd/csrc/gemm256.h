@@ -122,6 +122,13 @@ template <> struct Frag4<true> {
 // combined (DPP / permlane, fixed order) and colsum_out(part_row, j, sums) writes one partial row per (row tile, wave row) -- the bias
 // gradient of the layer whose dY this GEMM's output is, without a separate pass over it (fc1: the fc2 data-gradient GEMM emits dpre).
 template <class Epi> struct epi_colsum { static constexpr bool value = false; };
+// Which 8 columns a lane handles in the epilogue.  Default (HI_OFF absent = 4): 8 consecutive columns -- one 16-byte store per lane for bf16
+// outputs, eight lanes = one 128-byte row segment per instruction.  For fp32 outputs 8 consecutive columns are TWO 16-byte accesses per lane,
+// and each of them touches every other 16 bytes of the row segment: two instructions that each half-fill the same cache lines.  A functor
+// that declares `static constexpr int HI_OFF = 32` gets columns j..j+3 (lo) and j+32..j+35 (hi) instead: every load / store instruction of
+// the fp32 residual read-modify-write and of the weight-gradient slabs then covers whole 128-byte segments (round 5; same values, same bits).
+template <class Epi, class = void> struct epi_hi_off { static constexpr int value = 4; };
+template <class Epi> struct epi_hi_off<Epi, std::void_t<decltype(Epi::HI_OFF)>> { static constexpr int value = Epi::HI_OFF; };
 // ILV: how many of a phase's two LDS-DMA pieces are issued INSIDE the phase's MFMA segment instead of in front of its first barrier.
 // Between two barriers one wave row runs its MFMA segment (8 MFMAs = 256 cycles + the fragment wait) while the other runs its
 // load segment (fragment reads, 2 DMA issues at ~60-180 cycles each, the counted vmcnt wait); the barrier interval is the longer of
@@ -366,7 +373,9 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
     bar();                 // every wave's DMAs have landed and nobody reads the staging units any more
     {
         float* stg = reinterpret_cast<float*>(smem + wv * 8704);
-        const int lr = lane & 31, g = lane >> 5, rrow = lane >> 3, c0 = (lane & 7) * 8;
+        constexpr int HO = epi_hi_off<Epi>::value;
+        static_assert(HO == 4 || (HO == 32 && !epi_colsum<Epi>::value), "epilogue column layouts: 8 consecutive, or 4 + 4 at a distance of 32");
+        const int lr = lane & 31, g = lane >> 5, rrow = lane >> 3, c0 = (lane & 7) * (HO == 4 ? 8 : 4);
         const int jcol = j0 + wc * 64 + c0;
         const typename Epi::Col col = epi.col(jcol);
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
                 for (int st = 0; st < 4; ++st) {
                     const int r = st * 8 + rrow;
                     const float4 lo = *reinterpret_cast<const float4*>(stg + r * 68 + c0);
-                    const float4 hi = *reinterpret_cast<const float4*>(stg + r * 68 + c0 + 4);
+                    const float4 hi = *reinterpret_cast<const float4*>(stg + r * 68 + c0 + HO);
                     if constexpr (epi_colsum<Epi>::value) epi.store_cs(ib + r, jcol, lo, hi, col, rows[m2][st], split, cs);
                     else epi.store(ib + r, jcol, lo, hi, col, rows[m2][st], split);
                 }
