@@ -122,7 +122,7 @@ class KernelTimer:
         "gemm256_dgrad": "g256::gemm256_kernel<false,true,*> (nn.Linear data gradient dX = dY.W)",
         "gemm256_wgrad": "g256::gemm256_kernel<true,true,Epi4Slab> + slab_reduce (weight gradient dW = dY^T.X)",
         "attention_fwd": "a3::fwd_kernel (fused attention forward, rel-pos bias on the matrix pipe; head_dim 80: a2::fwd_kernel<1,1,80>)",
-        "attention_bwd": "a3::bwd_dq_kernel (rel-pos table gradient contracted inside) + a3::bwd_dkv_kernel + prep_delta (fused attention backward; head_dim 80: a2::bwd_dq_kernel<2,2,80,WP32> + a2::bwd_dkv_kernel<2,80> + delta)",
+        "attention_bwd": "a3::bwd_dq_kernel (Delta = rowsum(dO * O) in its prologue, rel-pos table gradient contracted inside) + a3::bwd_dkv_kernel (fused attention backward; head_dim 80: a2::bwd_dq_kernel<2,2,80,WP32> + a2::bwd_dkv_kernel<2,80> + the delta launch)",
     }
 
     def __init__(self, ops_mod):
