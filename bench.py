@@ -175,7 +175,10 @@ def _algorithmic_bytes():
     return {
         "fc1": {"bytes": R * D * 2 + Hd * D * 2 + 2 * R * Hd * 2, "what": "X [R, D] + W [4D, D] in; act + gelu' [R, 4D] out"},
         "wgrad": {"bytes": R * Hd * 2 + R * D * 2 + 4 * Hd * D, "what": "fc1 / fc2 weight gradient: dY [R, 4D] + X [R, D] in; dW fp32 [4D, D] out (split-K slabs and their reduction are overhead, not algorithm)"},
-        "dgrad": {"bytes": R * D * 2 * 2 + D * D * 2, "what": "proj data gradient: dY [R, D] + W [D, D] in; dX [R, D] out (the family's most frequent instantiation)"},
+        # the PMC family is keyed by kernel + grid: the three data gradients with a [R, D] output (qkv: K = 3D, proj: K = D, fc1: K = 4D), one of
+        # each per block -- the measured figure is their average, so is this one (round 5; the proj-only figure made the ratio look like 2.6)
+        "dgrad": {"bytes": (R * (3 * D + D + Hd) * 2 + (3 * D + D + Hd) * D * 2 + 3 * R * D * 2) // 3,
+                  "what": "average of the qkv / proj / fc1 data gradients (one each per block, same grid): dY [R, 3D | D | 4D] + W in; dX [R, D] out"},
         "attn_fwd": {"bytes": 3 * qkv + qkv + BH * L * 4 + tables, "what": "q, k, v in; out, lse, bias tables (kept for the backward) out"},
         "attn_bwd_dq": {"bytes": 3 * qkv + qkv + tables + qkv, "what": "q, k, v, dO, tables in; dQ out (+ the [166, 64] table gradient)"},
         "attn_bwd_dkv": {"bytes": 3 * qkv + qkv + tables + 2 * qkv, "what": "q, k, v, dO, tables in; dK, dV out"},

@@ -26,7 +26,7 @@ namespace g256 {
 
 constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
 constexpr int LDS_BYTES = 131072;
-// diagnostics (pa_debug_set): [0] first-round de-phasing in shader cycles, [1] drop epilogue stores, [2] 1 = plain row-major tile order, [3] wgrad workgroup target
+// diagnostics (pa_debug_set): [0] first-round de-phasing in shader cycles, [1] drop epilogue stores, [2] 1 = plain row-major tile order, 2 = blocked order with split = blockIdx.y (the pre-round-5 split-K assignment), [3] wgrad workgroup target
 inline int g_dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // [5] (G256_ILV_AB builds) 1 + ILV schedule override
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
@@ -165,13 +165,26 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
     // tiles sharing an A row panel hit the same L2.
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
-    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    int split = blockIdx.y;
+    // Split-K launches (the weight gradients; round 5): the workgroups are dispatched x-fastest over (tiles, splits) and land on XCD
+    // (linear id) % 8.  With split = blockIdx.y every XCD used to hold an eighth of the tiles of EVERY split, so each of the 8 L2s pulled
+    // all K slabs of its operand panels: the fc1 weight gradient read 431 MB where 129 are algorithmic (PMC, profiles/roofline_traffic.json).
+    // Now the (split, tile) list -- split-major -- is cut into 8 contiguous runs, one per XCD: an XCD holds one split (or a few whole ones,
+    // or a part of one) and inside it a compact patch of tiles, so a K slab of the operands goes through as few L2s as the sizes allow.
+    // Needs the workgroup count to be a multiple of 8; order 2 (g_dbg[2]) keeps the old assignment for A/B.
+    if (gridDim.y > 1 && order == 0 && ((nwg * gridDim.y) & 7) == 0) {
+        const int lin = blockIdx.y * nwg + bid;
+        const int w = (lin & 7) * ((nwg * (int)gridDim.y) >> 3) + (lin >> 3);
+        split = w / nwg;
+        tile = w - split * nwg;
+    }
     // Inside the run the tiles are ordered in blocks of TR row panels x TC column panels (row groups of TR panels, column blocks of TC,
     // then row-major inside a block), so that the ~32 tiles an XCD has in flight form a TR x TC patch: per contraction step they pull
     // TR + TC operand panels through that XCD's L2 instead of 2 + tiles_n (fc1 forward, 16 column panels: FETCH_SIZE 251 -> ~165 MB
     // per launch; the weight matrix alone is twice the L2).  g_dbg[2] = 1 restores the plain row-major order (A/B).
     int tm, tn;
-    if (order == 0) {
+    if (order != 1) {
         constexpr int TR = 4, TC = 8;
         const int tiles_m = (M + BMR - 1) / BMR;
         const int per_group = TR * tiles_n;
@@ -193,7 +206,6 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
     }
     const int i0 = tm * BMR, j0 = tn * BN;
     const bool blk3 = !(SHORT && wr == 1);          // does this wave own the fourth 32-row block of its 128 rows?  (wave-uniform)
-    const int split = blockIdx.y;
     const int kt0 = split * ktiles_per_split;
     const int nt = min(ktiles - kt0, ktiles_per_split);
 
