@@ -642,16 +642,23 @@ def main():
     #              the gradients when our autograd node returns them all at once, i.e. NO overlap with the backward -- the floor
     n_ranks = torch.distributed.get_world_size() if distributed else 1
     variants = {}
+    gs_errors = {}
     ddp_error = None
     arrangement = "n/a"
     if not distributed:
         dt, lossv = timed_region()
     else:
         todo = ["per_block", "coarse", "ddp"] if args.gradsync == "all" else [args.gradsync]
+        gs_errors = {}
         for name in [v for v in todo if v != "ddp"]:
-            model.grad_sync = parallel.GradSync(mode=name)
-            d_, l_ = timed_region()
-            variants[name] = {"seconds": d_, "loss": l_, "collective_launches_per_step": model.grad_sync.launches // (args.steps + args.warmup)}
+            try:                                            # one arrangement failing at the Python level (the same on every rank) leaves the others
+                model.grad_sync = parallel.GradSync(mode=name)
+                d_, l_ = timed_region()
+                variants[name] = {"seconds": d_, "loss": l_, "collective_launches_per_step": model.grad_sync.launches // (args.steps + args.warmup)}
+            except (TypeError, ValueError, AttributeError, NotImplementedError) as e:
+                gs_errors[name] = "%s: %s" % (type(e).__name__, str(e)[:200])
+        if gs_errors and not variants and "ddp" not in todo:
+            raise RuntimeError("every gradient-exchange arrangement failed: %r" % gs_errors)
         gs_best = min((v for v in variants), key=lambda v: variants[v]["seconds"]) if variants else None
 
     # ---- sustained region (below) runs under the better GradSync arrangement; the DDP wrapper is timed after it (its reducer hooks stay on
@@ -811,6 +818,8 @@ def main():
             out["extra"] = dict(out["extra"] or {}, gradsync_variants=variants, gradsync_chosen=arrangement)
             if ddp_error:
                 out["extra"]["gradsync_ddp_error"] = ddp_error
+            if gs_errors:
+                out["extra"]["gradsync_errors"] = gs_errors
         if n_ranks == 1 and args.dtype == "bf16" and not args.no_optimizer and args.model == "vit_large":
             out["optimizer_step"] = optimizer_step_ms(model, step)
         if n_ranks == 1 and not distributed and args.dtype == "bf16" and args.model == "vit_large" and not args.no_secondary:
