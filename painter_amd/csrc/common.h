@@ -122,6 +122,10 @@ inline int g_attn3_fuse = 0;
 // pa_debug_set(8, v): 0 = default (light attention workgroups NOT dispatched last unless PA_ATTN_LIGHT_LAST=1; round 5), 1 = off, 2 = on
 inline int g_attn_light_last = 0;
 
+// pa_debug_set(5, v): LayerNorm backward variant: 0 = default (rows split over the 4 waves of a workgroup wherever D >= 1024), 1 = one wave per
+// row everywhere (the kernel of rounds 1 - 4; still what narrow D runs)
+inline int g_ln_bwd_variant = 0;
+
 // pa_debug_set(9, n): tests only -- cap on the number of workgroups of the conv3x3 weight-gradient kernel (0 = the product's 512): with a small
 // cap every workgroup walks many tiles, through both ring phases and across column-strip boundaries, at test sizes
 inline int g_conv_wgrad_groups = 0;

@@ -551,6 +551,7 @@ extern "C" int pa_abi_version(void) { return PA_ABI_VERSION; }
 extern "C" int pa_debug_get(int which) {
     if (which < 0 || which > 9) return -1;
     if (which == 9) return g_conv_wgrad_groups;
+    if (which == 5) return g_ln_bwd_variant;
     if (which == 6) return g_relpos_splits;
     if (which == 7) return g_attn3_fuse;
     if (which == 8) return g_attn_light_last;
@@ -560,6 +561,7 @@ extern "C" int pa_debug_set(int which, int value) {
     if (which < 0 || which > 9) return (int)hipErrorInvalidValue;
     if (which < 8) g256::g_dbg[which] = value;
     if (which == 9) g_conv_wgrad_groups = value;
+    if (which == 5) g_ln_bwd_variant = value;
     if (which == 6) g_relpos_splits = value;
     if (which == 7) g_attn3_fuse = value;
     if (which == 8) g_attn_light_last = value;

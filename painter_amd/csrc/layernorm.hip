@@ -154,6 +154,147 @@ __global__ __launch_bounds__(256, NI <= 4 ? 4 : 2) void ln_bwd_kernel(const T* _
     }
 }
 
+// ---- round 5: the same backward with each ROW split over the workgroup's 4 waves (D >= 1024) ----------------------------------------------
+// One wave per row kept 64 registers of parameter-gradient accumulators per lane (gamma, d-gamma, d-beta, column sum: 4 float4 each at
+// D = 1024) next to the row itself, ran its two memory round trips (dy / x, then the residual gradient) back to back and had no registers
+// left to start the next row: 4.1 TB/s where the stream could go faster (waves waiting on memory 86 % of the time, PMC).  Here thread t
+// owns columns 4t .. 4t+3 (+ 1024 j) of EVERY row its workgroup handles: 4 accumulators of one float4, RB (= 2) rows per batch in registers, the
+// next batch's loads -- residual gradient included -- issued before the current one is reduced, row statistics combined through 128 bytes
+// of LDS (one barrier per batch, two slots), and no cross-wave reduction of the partial rows at the end: every column has one owner.
+// Batches go to workgroups in contiguous, equal runs (G = ceil(batches / k) <= the resident capacity), so nobody waits for a second round.
+DEVI uint2 raw4(const bf16* p) { return *reinterpret_cast<const uint2*>(p); }
+DEVI float4 raw4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+DEVI float4 cvt4(uint2 u) { return make_float4(bf16_lo(u.x), bf16_hi(u.x), bf16_lo(u.y), bf16_hi(u.y)); }
+DEVI float4 cvt4(float4 v) { return v; }
+template <typename T> struct Raw4 { typedef float4 type; };
+template <> struct Raw4<bf16> { typedef uint2 type; };
+
+template <typename T, int NJ, int RB, int OCC, bool CS>
+__global__ __launch_bounds__(256, OCC) void ln_bwd_rows_kernel(const T* __restrict__ dy, size_t lddy, const float* __restrict__ x, size_t ldx,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* dres, float* dx, size_t lddx,
+                                                          T* dxT, size_t lddxT, const float* __restrict__ rowscale, int rps,
+                                                          float* __restrict__ part, int R, int D, int nbatch) {
+    typedef typename Raw4<T>::type RawT;
+    constexpr int NP = CS ? 3 : 2;
+    __shared__ float red[2][4][RB][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b0 = (int)((long long)blockIdx.x * nbatch / gridDim.x), b1 = (int)((long long)(blockIdx.x + 1) * nbatch / gridDim.x);
+    int col[NJ];
+    bool on[NJ];
+    float4 g[NJ], ag[NJ], ab[NJ], ac[CS ? NJ : 1];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        col[j] = tid * 4 + 1024 * j;
+        on[j] = col[j] < D;
+        g[j] = on[j] ? load4(gamma + col[j]) : make_float4(0, 0, 0, 0);
+        ag[j] = make_float4(0, 0, 0, 0);
+        ab[j] = make_float4(0, 0, 0, 0);
+        if constexpr (CS) ac[j] = make_float4(0, 0, 0, 0);
+    }
+    const float invD = 1.f / (float)D;
+    RawT ndy[RB][NJ];
+    float4 nx[RB][NJ], nr[RB][NJ];
+    float nmu[RB], nrs[RB], nsc[RB];
+    auto fetch = [&](int b) {
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int row = min(b * RB + r, R - 1);              // a clamped (repeated) last row is loaded and dropped
+            nmu[r] = mean[row];
+            nrs[r] = rstd[row];
+            nsc[r] = (dxT && rowscale) ? rowscale[row / rps] : 1.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (on[j]) {
+                    ndy[r][j] = raw4(dy + (size_t)row * lddy + col[j]);
+                    nx[r][j] = load4(x + (size_t)row * ldx + col[j]);
+                    if (dres) nr[r][j] = load4(dres + (size_t)row * lddx + col[j]);
+                }
+        }
+    };
+    if (b0 < b1) fetch(b0);
+    int par = 0;
+    for (int b = b0; b < b1; ++b) {
+        RawT cdy[RB][NJ];
+        float4 cx[RB][NJ], cr[RB][NJ];
+        float mu[RB], rs[RB], sc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            mu[r] = nmu[r]; rs[r] = nrs[r]; sc[r] = nsc[r];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) { cdy[r][j] = ndy[r][j]; cx[r][j] = nx[r][j]; cr[r][j] = nr[r][j]; }
+        }
+        if (b + 1 < b1) fetch(b + 1);
+        float4 d[RB][NJ], xh[RB][NJ];
+        float s1[RB], s2[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const bool live = b * RB + r < R;                    // workgroup-uniform
+            s1[r] = 0.f;
+            s2[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                d[r][j] = make_float4(0, 0, 0, 0);
+                xh[r][j] = make_float4(0, 0, 0, 0);
+                if (on[j] && live) {
+                    const float4 dv = cvt4(cdy[r][j]), xv = cx[r][j];
+                    const float4 h = make_float4((xv.x - mu[r]) * rs[r], (xv.y - mu[r]) * rs[r], (xv.z - mu[r]) * rs[r], (xv.w - mu[r]) * rs[r]);
+                    ag[j].x += dv.x * h.x; ag[j].y += dv.y * h.y; ag[j].z += dv.z * h.z; ag[j].w += dv.w * h.w;
+                    ab[j].x += dv.x; ab[j].y += dv.y; ab[j].z += dv.z; ab[j].w += dv.w;
+                    const float4 q = make_float4(dv.x * g[j].x, dv.y * g[j].y, dv.z * g[j].z, dv.w * g[j].w);      // dxhat
+                    s1[r] += (q.x + q.y) + (q.z + q.w);
+                    s2[r] += (q.x * h.x + q.y * h.y) + (q.z * h.z + q.w * h.w);
+                    d[r][j] = q;
+                    xh[r][j] = h;
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            s1[r] = wave_sum(s1[r]);
+            s2[r] = wave_sum(s2[r]);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                red[par][wave][r][0] = s1[r];
+                red[par][wave][r][1] = s2[r];
+            }
+        }
+        __syncthreads();           // a thread is at most one barrier ahead of another: batch b + 1 writes the other slot, batch b + 2 comes after every read of b
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int row = b * RB + r;
+            if (row >= R) break;
+            const float c1 = ((red[par][0][r][0] + red[par][1][r][0]) + (red[par][2][r][0] + red[par][3][r][0])) * invD;
+            const float c2 = ((red[par][0][r][1] + red[par][1][r][1]) + (red[par][2][r][1] + red[par][3][r][1])) * invD;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                if (on[j]) {
+                    const float4 q = d[r][j], h = xh[r][j];
+                    float4 o = make_float4(rs[r] * (q.x - c1 - h.x * c2), rs[r] * (q.y - c1 - h.y * c2),
+                                           rs[r] * (q.z - c1 - h.z * c2), rs[r] * (q.w - c1 - h.w * c2));
+                    if (dres) { o.x += cr[r][j].x; o.y += cr[r][j].y; o.z += cr[r][j].z; o.w += cr[r][j].w; }
+                    *reinterpret_cast<float4*>(dx + (size_t)row * lddx + col[j]) = o;
+                    if (dxT) store4<T>(dxT + (size_t)row * lddxT + col[j], o.x * sc[r], o.y * sc[r], o.z * sc[r], o.w * sc[r]);
+                    if constexpr (CS) {
+                        ac[j].x = fmaf(o.x, sc[r], ac[j].x); ac[j].y = fmaf(o.y, sc[r], ac[j].y);
+                        ac[j].z = fmaf(o.z, sc[r], ac[j].z); ac[j].w = fmaf(o.w, sc[r], ac[j].w);
+                    }
+                }
+        }
+        par ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (on[j]) {
+            float* pr = part + (size_t)blockIdx.x * NP * D + col[j];
+            *reinterpret_cast<float4*>(pr) = ag[j];
+            *reinterpret_cast<float4*>(pr + D) = ab[j];
+            if constexpr (CS) *reinterpret_cast<float4*>(pr + 2 * D) = ac[j];
+        }
+}
+
 extern "C" int pa_slab_reduce(const float* in, float* out, int64_t n, int nz, int64_t stride, int accumulate, hipStream_t st);
 int pa_slab_reduce2(const float* in, float* out0, float* out1, int64_t n0, int64_t n, int nz, int64_t stride, hipStream_t st);   // gemm.hip
 
@@ -179,22 +320,49 @@ extern "C" int pa_layernorm_fwd(int dtype, const float* x, int64_t ldx, const fl
     return ln_fwd_t<float>(x, ldx, gamma, beta, eps, (float*)y, ldy, mean, rstd, R, D, st);
 }
 
-static int ln_bwd_blocks(int R) {
+static int ln_bwd_blocks_wave(int R) {
     int b = (R + 3) / 4;
     return b > 1024 ? 1024 : b;      // 4 waves per SIMD resident on 256 CUs
 }
-extern "C" int64_t pa_layernorm_bwd_workspace_bytes(int R, int D) { return (int64_t)ln_bwd_blocks(R) * 3 * D * sizeof(float); }
+// row-split kernel: RB rows per batch, OCC workgroups resident per CU
+// batches of 2 rows; 4 workgroups per CU at D <= 1024 (98 registers), 3 with two column groups per thread (1024 < D <= 2048).  Measured in
+// the ViT-L step against one wave per row (profiles/r05_ab_layernorm_bwd_rows_split.log): 4-row batches / 3 per CU -0.59 ms, 2-row batches /
+// 4 per CU -0.68 ms, 2-row batches / 5 per CU +0.15 ms (6 spilled registers and 1255 short workgroups).
+constexpr int LNB_RB = 2;
+static int lnb_occ(int D) { return D <= 1024 ? 4 : 3; }
+static bool ln_bwd_rows_ok(int D) { return g_ln_bwd_variant != 1 && D >= 1024 && D <= 2048; }
+static int ln_bwd_blocks_rows(int R, int D) {
+    const int nbatch = (R + LNB_RB - 1) / LNB_RB, cap = 256 * lnb_occ(D);
+    const int k = (nbatch + cap - 1) / cap;                     // batches per workgroup
+    return (nbatch + k - 1) / k;
+}
+static int ln_bwd_blocks(int R, int D) { return ln_bwd_rows_ok(D) ? ln_bwd_blocks_rows(R, D) : ln_bwd_blocks_wave(R); }
+// (sized for either variant: the knob may change between the call that sized a caller-owned buffer and the launch)
+extern "C" int64_t pa_layernorm_bwd_workspace_bytes(int R, int D) {
+    const int a = ln_bwd_blocks_wave(R), b = ln_bwd_blocks_rows(R, D);
+    return (int64_t)(a > b ? a : b) * 3 * D * sizeof(float);
+}
 
 template <typename T>
 static int ln_bwd_t(const T* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean, const float* rstd,
                     const float* gamma, const float* dres, float* dx, int64_t lddx, T* dxT, int64_t lddxT,
                     const float* rowscale, int rps, float* dgamma_dbeta, float* dxT_colsum, float* ws, int R, int D, hipStream_t st) {
     const int ni = (D + 255) / 256;
-    const int nb = ln_bwd_blocks(R);
+    const int nb = ln_bwd_blocks(R, D);
     dim3 grid(nb), blk(256);
     const bool cs = dxT_colsum != nullptr;       // (with dgamma_dbeta == NULL: any non-NULL value selects the column-sum partials)
     if (cs && dxT == nullptr) return (int)hipErrorInvalidValue;
     const int np = cs ? 3 : 2;
+    if (ln_bwd_rows_ok(D)) {
+        const int nbatch = (R + LNB_RB - 1) / LNB_RB;
+#define LN_ROWS(NJ, OCC_, CS_) PA_LAUNCH((ln_bwd_rows_kernel<T, NJ, LNB_RB, OCC_, CS_>), grid, blk, 0, st, dy, (size_t)lddy, x, (size_t)ldx, mean, rstd, gamma, dres, dx, (size_t)lddx, dxT, (size_t)lddxT, rowscale, rps, ws, R, D, nbatch)
+        if (D <= 1024) { if (cs) LN_ROWS(1, 4, true); else LN_ROWS(1, 4, false); }
+        else { if (cs) LN_ROWS(2, 3, true); else LN_ROWS(2, 3, false); }
+#undef LN_ROWS
+        int e = (int)hipGetLastError();
+        if (e || dgamma_dbeta == nullptr) return e;
+        return pa_slab_reduce2(ws, dgamma_dbeta, dxT_colsum, 2 * D, np * D, nb, np * D, st);
+    }
     const size_t sm = (size_t)8 * D * sizeof(float);          // <= 64 KB for every D the kernel takes (NI <= 8: D <= 2048)
     // (round 5: non-temporal loads of the read-once streams -- x saved by the forward, dy from the GEMM in front -- measured 53.11 vs 53.25 ms
     // per step, inside the noise: profiles/r05_ab_layernorm_bwd_nt_loads.log; not kept)
@@ -217,7 +385,7 @@ static int ln_bwd_t(const T* dy, int64_t lddy, const float* x, int64_t ldx, cons
 extern "C" int pa_layernorm_bwd_reduce(const void* workspace, float* dgamma_dbeta, float* dxT_colsum, int with_colsum, int R, int D, hipStream_t st) {
     if (workspace == nullptr || dgamma_dbeta == nullptr || (with_colsum && dxT_colsum == nullptr)) return (int)hipErrorInvalidValue;
     const int np = with_colsum ? 3 : 2;
-    return pa_slab_reduce2((const float*)workspace, dgamma_dbeta, dxT_colsum, 2 * D, np * D, ln_bwd_blocks(R), np * D, st);
+    return pa_slab_reduce2((const float*)workspace, dgamma_dbeta, dxT_colsum, 2 * D, np * D, ln_bwd_blocks(R, D), np * D, st);
 }
 // dgamma_dbeta: [2, D] fp32 (dgamma then dbeta), overwritten.
 extern "C" int pa_layernorm_bwd(int dtype, const void* dy, int64_t lddy, const float* x, int64_t ldx, const float* mean,

@@ -251,8 +251,23 @@ def test_linear_strided_views_and_pixshuf(T):
 
 
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("R,D", [(64, 128), (1000, 1024), (25088, 1024), (33, 1280)])
-def test_layernorm_fwd_bwd(T, R, D):
+@pytest.mark.parametrize("R,D", [(64, 128), (1000, 1024), (1003, 1024), (25088, 1024), (33, 1280), (4099, 1280)])
+@pytest.mark.parametrize("variant", [0, 1])
+def test_layernorm_fwd_bwd(T, R, D, variant):
+    """variant (pa_debug_set(5, .)): 0 = the default backward (rows split over the workgroup's waves wherever D >= 1024, batches of 2 rows;
+    R = 1003 / 33 / 4099 end in a half-filled batch), 1 = one wave per row everywhere (what D = 128 always runs)."""
+    from painter_amd._lib import lib
+    if variant == 1 and D < 1024:
+        pytest.skip("narrow rows run the one-wave-per-row kernel under either setting")
+    saved = lib.pa_debug_get(5)
+    lib.pa_debug_set(5, variant)
+    try:
+        _layernorm_fwd_bwd(T, R, D)
+    finally:
+        lib.pa_debug_set(5, saved)
+
+
+def _layernorm_fwd_bwd(T, R, D):
     x = gen((R, D), 1, 2.0) + 0.3
     gamma = 1 + gen((D,), 2, 0.1)
     beta = gen((D,), 3, 0.1)
