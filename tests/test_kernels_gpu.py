@@ -251,14 +251,12 @@ def test_linear_strided_views_and_pixshuf(T):
 
 
 @pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("R,D", [(64, 128), (1000, 1024), (1003, 1024), (25088, 1024), (33, 1280), (4099, 1280)])
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("R,D,variant", [(64, 128, 0), (1000, 1024, 0), (1003, 1024, 0), (25088, 1024, 0), (33, 1280, 0), (4099, 1280, 0),
+                                         (1000, 1024, 1), (1003, 1024, 1), (25088, 1024, 1), (33, 1280, 1), (4099, 1280, 1)])
 def test_layernorm_fwd_bwd(T, R, D, variant):
     """variant (pa_debug_set(5, .)): 0 = the default backward (rows split over the workgroup's waves wherever D >= 1024, batches of 2 rows;
     R = 1003 / 33 / 4099 end in a half-filled batch), 1 = one wave per row everywhere (what D = 128 always runs)."""
     from painter_amd._lib import lib
-    if variant == 1 and D < 1024:
-        pytest.skip("narrow rows run the one-wave-per-row kernel under either setting")
     saved = lib.pa_debug_get(5)
     lib.pa_debug_set(5, variant)
     try:
