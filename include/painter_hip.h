@@ -44,7 +44,8 @@ int pa_abi_version(void);
  * 1 drop that kernel's epilogue stores (never set by the product path); 2 = tile order of that kernel: 0 blocked 4 x 8 patches per XCD and, for
  * split-K launches, one contiguous (split, tile) run per XCD (default), 1 plain row-major, 2 blocked with split = blockIdx.y (before round 5); 3 = TUNING, set by the engine: target number of workgroups
  * of the weight-gradient GEMM (0 = 256, the whole chip; 64 when the weight gradients run on a side stream); 4 = row-tile height of the un-split bf16
- * GEMMs: 0 by rule (224 rows where that fills the last round of workgroups better), 1 always 256, 2 224 wherever possible; 6 = K splits of the
+ * GEMMs: 0 by rule (224 rows where that fills the last round of workgroups better), 1 always 256, 2 224 wherever possible; 5 = LayerNorm backward:
+ * 0 rows split over the workgroup's waves wherever D >= 1024 (default), 1 one wave per row everywhere (the kernel of rounds 1 - 4); 6 = K splits of the
  * rel-pos table-gradient GEMM; 7 = rel-pos table gradient inside the generation-3 dQ kernel: 0 default (on), 1 off, 2 on (tests);
  * 8 = generation-3 attention: workgroups with idle waves dispatched last: 0 default (off since round 5), 1 off, 2 on;
  * 9 = tests: cap on the workgroups of the conv3x3 weight-gradient kernel (0 = 512), so that small images make a workgroup walk many tiles. */
