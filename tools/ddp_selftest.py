@@ -34,6 +34,10 @@ def main():
     ga, la = grads(parallel.GradSync())
     gb, lb = grads(None)
     gc, lc = grads(None)
+    gd, ld = grads(parallel.GradSync(mode="coarse"))        # round 5: the four coalesced launches (dist.all_reduce_coalesced with AVG on RCCL)
+    coarse_bad = [n for n in gd if not torch.equal(gd[n], gb[n])]
+    print("coarse arrangement: mismatching", len(coarse_bad), coarse_bad[:8], "collective launches", m.grad_sync.launches, flush=True)
+    assert not coarse_bad and ld == lb
     bad = [n for n in ga if not torch.equal(ga[n], gb[n])]
     nondet = [n for n in gb if not torch.equal(gb[n], gc[n])]
     worst = max([float((ga[n] - gb[n]).abs().max() / gb[n].abs().max().clamp_min(1e-30)) for n in bad] + [0.0])
