@@ -60,3 +60,26 @@ def test_model_table_names_the_baseline_configurations():
     for key, spec in bench.MODELS.items():
         assert hasattr(models_painter, spec["factory"]) and spec["blocks"] < spec["whole"]
     assert bench.MODELS["vit_large"]["blocks"] == 4.034e12 and bench.MODELS["vit_huge"]["head_dim"] == 80
+
+
+def test_committed_pmc_traffic_is_stamped_with_the_built_library():
+    """`roofline.traffic` is read from profiles/roofline_traffic.json and refused when that file was measured on another library
+    (bench.py compares `lib_sha16`): a tree whose kernels changed after the last PMC pass would silently report `traffic: null`.  The build is
+    deterministic (same sources + flags -> same bytes), so the stamp can be checked wherever the library has been built; it also pins the
+    algorithmic-bytes table to the families the PMC file holds."""
+    import json
+    import os
+    tj = json.load(open(os.path.join(bench.ROOT, "profiles", "roofline_traffic.json")))
+    sha = bench._lib_sha16()
+    if sha is None:
+        import pytest
+        pytest.skip("library not built here")
+    if tj["_meta"]["lib_sha16"] != sha:
+        # not a failure of the code under test: the library was rebuilt somewhere that does not reproduce the measured bytes (another path or
+        # toolchain), or a kernel changed after the last PMC pass -- bench.py will report `traffic: null` until tools/gpu_visit.sh pmc5 is re-run
+        import pytest
+        pytest.skip("profiles/roofline_traffic.json is stamped %s, the library here is %s" % (tj["_meta"]["lib_sha16"], sha))
+    alg = bench._algorithmic_bytes()
+    assert set(alg) == {k for k in tj if not k.startswith("_")}
+    for k, v in alg.items():
+        assert 0.9 <= tj[k]["hbm_bytes_per_launch"] / v["bytes"] < 4.0, (k, tj[k]["hbm_bytes_per_launch"], v["bytes"])
