@@ -60,6 +60,7 @@ for s in "$@"; do
     lnvar)     timeout 600 python tools/step_knob_ab.py 5 6 "LN bwd 4-row batches, 3 per CU:5=0" "one wave per row:5=1" "2-row batches, 4 per CU:5=2" "2-row batches, 5 per CU:5=3" > gpurun_out/lnvar_ab.log 2>&1; echo "ab rc=$?"; tail -5 gpurun_out/lnvar_ab.log ;;
     lastcheck) timeout 500 python -m pytest tests/test_kernels_gpu.py tests/test_parallel_gpu.py -m gpu -q -k "layernorm or bench or GradSync" > gpurun_out/lastcheck.log 2>&1; echo "lastcheck rc=$?"; tail -3 gpurun_out/lastcheck.log ;;
     selftest)  PAINTER_AMD_DDP_SELFTEST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29547 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python tools/ddp_selftest.py > gpurun_out/selftest.log 2>&1; echo "selftest rc=$?"; tail -4 gpurun_out/selftest.log ;;
+    profhuge)  (cd /tmp && PAINTER_AMD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_huge -o huge -- python $OLDPWD/bench.py --model vit_huge --steps 3 --warmup 1 --no-cpu-baseline --no-optimizer --no-reference-gpu --no-secondary --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_huge.log 2>&1); echo "profhuge done"; ls gpurun_out/prof_huge | head -3 ;;
     adopt)     cp gpurun_out/roofline_traffic.json profiles/roofline_traffic.json && echo "adopted the PMC traffic of this library for the bench line of this visit" ;;
     engab)     timeout 600 python tools/step_engine_ab.py 5 6 "delta in dQ + colsum in epilogue (default):_ATTN_PREP=fused,_FC1_COLSUM=epilogue" "prep launch:_ATTN_PREP=launch,_FC1_COLSUM=epilogue" "separate fc1 column sums:_ATTN_PREP=fused,_FC1_COLSUM=separate" > gpurun_out/engab.log 2>&1; echo "engab rc=$?"; tail -4 gpurun_out/engab.log ;;
     libab)     timeout 900 python tools/step_lib_ab.py 3 6 "round-5 build=painter_amd/lib/libpainter_hip.so" "baseline build=painter_amd/lib/libpainter_hip_base.so" > gpurun_out/libab.log 2>&1; echo "libab rc=$?"; tail -4 gpurun_out/libab.log ;;
