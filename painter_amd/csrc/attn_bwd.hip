@@ -18,14 +18,35 @@
 #include "attn3.h"
 
 // ------------------------------------------------------------------------------- Delta pre-pass
-// one wave per row; a group of GL = hd / 16 consecutive lanes covers one head (16 elements per lane)
-template <typename T> __global__ void attn_delta_kernel(const T* o, size_t ldo, const T* d_o, size_t lddo, float* delta, int R, int L, int H, int hd) {
+// one wave per row; 16 elements per lane.  head_dim 64: a group of 4 consecutive lanes covers one head (DPP combine).  Any other
+// head_dim % 16 == 0 (80: ViT-H/14, whose attention has been on a timed path since round 4): the head_dim / 16 partial sums of a head are
+// combined in ascending order by one lane through LDS.  (Until the end of round 5 that branch was "one lane per head": 16 of 64 lanes active
+// with 80 scalar loads each -- 96 us per launch for 42 MB, 3.1 ms of the ViT-H/14 step; profiles/r05_vit_huge_one_stream_kernel_stats.csv.)
+template <typename T> DEVI void load16(const T* p, float* v);           // 16 consecutive elements from a 16-byte aligned address
+template <> DEVI void load16<bf16>(const bf16* p, float* v) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 8);
+    v[0] = bf16_lo(a.x); v[1] = bf16_hi(a.x); v[2] = bf16_lo(a.y); v[3] = bf16_hi(a.y);
+    v[4] = bf16_lo(a.z); v[5] = bf16_hi(a.z); v[6] = bf16_lo(a.w); v[7] = bf16_hi(a.w);
+    v[8] = bf16_lo(b.x); v[9] = bf16_hi(b.x); v[10] = bf16_lo(b.y); v[11] = bf16_hi(b.y);
+    v[12] = bf16_lo(b.z); v[13] = bf16_hi(b.z); v[14] = bf16_lo(b.w); v[15] = bf16_hi(b.w);
+}
+template <> DEVI void load16<float>(const float* p, float* v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float4 a = *reinterpret_cast<const float4*>(p + 4 * i);
+        v[4 * i] = a.x; v[4 * i + 1] = a.y; v[4 * i + 2] = a.z; v[4 * i + 3] = a.w;
+    }
+}
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const T* o, size_t ldo, const T* d_o, size_t lddo, float* delta, int R, int L, int H, int hd) {
+    __shared__ float part[4][128];              // head_dim != 64: one partial sum per 16-element chunk of the wave's row (D <= 2048)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
-    if (row >= R) return;
-    const int b = row / L, l = row % L;
+    const bool live = row < R;                  // (no early return: the general branch has a workgroup barrier)
+    const int b = live ? row / L : 0, l = live ? row % L : 0;
     const int D = H * hd;
     if (hd == 64) {
+        if (!live) return;
         for (int c = lane * 16; c < D; c += 1024) {
             float s = 0.f;
 #pragma unroll
@@ -33,22 +54,48 @@ template <typename T> __global__ void attn_delta_kernel(const T* o, size_t ldo, 
             s = quad_sum(s);
             if ((lane & 3) == 0) delta[((size_t)b * H + c / 64) * L + l] = s;
         }
-    } else {                                    // any hd % 16 == 0: one lane per head (not on a timed path: fixed summation order, no exchange)
-        for (int h = lane; h < H; h += 64) {
-            float s = 0.f;
-            for (int e = 0; e < hd; ++e) s += to_f(o[(size_t)row * ldo + h * hd + e]) * to_f(d_o[(size_t)row * lddo + h * hd + e]);
-            delta[((size_t)b * H + h) * L + l] = s;
+    } else {
+        const int nchunk = D / 16, gl = hd / 16;
+        if (live) {
+            for (int c = lane; c < nchunk; c += 64) {
+                float s = 0.f;
+                const T* po = o + (size_t)row * ldo + c * 16;
+                const T* pd = d_o + (size_t)row * lddo + c * 16;
+                if constexpr (VEC) {
+                    float a[16], g[16];
+                    load16<T>(po, a);
+                    load16<T>(pd, g);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s += a[e] * g[e];
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) s += to_f(po[e]) * to_f(pd[e]);
+                }
+                part[wave][c] = s;
+            }
+        }
+        __syncthreads();
+        if (live) {
+            for (int h = lane; h < H; h += 64) {
+                float s = 0.f;
+                for (int k = 0; k < gl; ++k) s += part[wave][h * gl + k];
+                delta[((size_t)b * H + h) * L + l] = s;
+            }
         }
     }
 }
 extern "C" int pa_attn_bwd_delta(int dtype, const void* out, int64_t ldo, const void* dout, int64_t lddo, float* delta, int batch, int L,
                                  int heads, int head_dim, hipStream_t st) {
     if (head_dim <= 0 || head_dim % 16) return (int)hipErrorInvalidValue;
+    if (head_dim != 64 && heads * head_dim > 2048) return (int)hipErrorInvalidValue;
     const int R = batch * L;
-    if (dtype == PA_BF16)
-        PA_LAUNCH(attn_delta_kernel<bf16>, dim3((R + 3) / 4), dim3(256), 0, st, (const bf16*)out, (size_t)ldo, (const bf16*)dout, (size_t)lddo, delta, R, L, heads, head_dim);
-    else
-        PA_LAUNCH(attn_delta_kernel<float>, dim3((R + 3) / 4), dim3(256), 0, st, (const float*)out, (size_t)ldo, (const float*)dout, (size_t)lddo, delta, R, L, heads, head_dim);
+    const size_t esz = dtype == PA_BF16 ? 2 : 4;
+    // 16-byte loads where both operands allow them (base address and row stride): always the case for the engine's tensors
+    const bool vec = ((uintptr_t)out % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((size_t)ldo * esz % 16 == 0) && ((size_t)lddo * esz % 16 == 0);
+#define PA_DELTA(T_, V_) PA_LAUNCH((attn_delta_kernel<T_, V_>), dim3((R + 3) / 4), dim3(256), 0, st, (const T_*)out, (size_t)ldo, (const T_*)dout, (size_t)lddo, delta, R, L, heads, head_dim)
+    if (dtype == PA_BF16) { if (vec) PA_DELTA(bf16, true); else PA_DELTA(bf16, false); }
+    else { if (vec) PA_DELTA(float, true); else PA_DELTA(float, false); }
+#undef PA_DELTA
     LAUNCH_CHECK();
 }
 

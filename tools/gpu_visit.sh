@@ -61,6 +61,11 @@ for s in "$@"; do
     lastcheck) timeout 500 python -m pytest tests/test_kernels_gpu.py tests/test_parallel_gpu.py -m gpu -q -k "layernorm or bench or GradSync" > gpurun_out/lastcheck.log 2>&1; echo "lastcheck rc=$?"; tail -3 gpurun_out/lastcheck.log ;;
     selftest)  PAINTER_AMD_DDP_SELFTEST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29547 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python tools/ddp_selftest.py > gpurun_out/selftest.log 2>&1; echo "selftest rc=$?"; tail -4 gpurun_out/selftest.log ;;
     profhuge)  (cd /tmp && PAINTER_AMD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_huge -o huge -- python $OLDPWD/bench.py --model vit_huge --steps 3 --warmup 1 --no-cpu-baseline --no-optimizer --no-reference-gpu --no-secondary --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_huge.log 2>&1); echo "profhuge done"; ls gpurun_out/prof_huge | head -3 ;;
+    hd80)      timeout 100 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -x -k "head_dim_80 or h14" > gpurun_out/hd80.log 2>&1; rc=$?; echo "hd80 rc=$rc"; tail -2 gpurun_out/hd80.log; [ $rc -eq 0 ] || exit 1 ;;
+    pmctraffic) (cd /tmp && for c in "FETCH_SIZE" "WRITE_SIZE"; do
+                  PAINTER_AMD_SIDE_STREAM=0 timeout 100 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OLDPWD/gpurun_out/pmc_$c -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --no-reference-gpu --no-secondary --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/pmc_$c.log 2>&1; done)
+               python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/roofline_traffic.json > gpurun_out/pmc_traffic.log 2>&1; echo "traffic rc=$?"
+               rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE ;;
     adopt)     cp gpurun_out/roofline_traffic.json profiles/roofline_traffic.json && echo "adopted the PMC traffic of this library for the bench line of this visit" ;;
     engab)     timeout 600 python tools/step_engine_ab.py 5 6 "delta in dQ + colsum in epilogue (default):_ATTN_PREP=fused,_FC1_COLSUM=epilogue" "prep launch:_ATTN_PREP=launch,_FC1_COLSUM=epilogue" "separate fc1 column sums:_ATTN_PREP=fused,_FC1_COLSUM=separate" > gpurun_out/engab.log 2>&1; echo "engab rc=$?"; tail -4 gpurun_out/engab.log ;;
     libab)     timeout 900 python tools/step_lib_ab.py 3 6 "round-5 build=painter_amd/lib/libpainter_hip.so" "baseline build=painter_amd/lib/libpainter_hip_base.so" > gpurun_out/libab.log 2>&1; echo "libab rc=$?"; tail -4 gpurun_out/libab.log ;;
