@@ -12,6 +12,9 @@ if ! timeout 120 python -c "import torch; x = torch.randn(1 << 20).cuda(); asser
 fi
 HEAD=${PAINTER_AMD_GIT_HEAD:-unknown}
 export PAINTER_AMD_GIT_HEAD=$HEAD
+# which library this visit measures: tools/adopt_profiles.py refuses to file anything from gpurun_out/ under profiles/ unless this hash is
+# the hash of the library the tree builds at that moment (round 6: the closing artefacts of rounds 4 and 5 trailed the closing commit)
+echo "$(sha256sum painter_amd/lib/libpainter_hip.so | cut -c1-16) $HEAD" > gpurun_out/visit_lib_sha16.txt
 for s in "$@"; do
   case $s in
     tests)     timeout 480 python -m pytest tests -m gpu -q -s > gpurun_out/tests.log 2>&1; echo "tests rc=$?"; tail -5 gpurun_out/tests.log ;;

@@ -50,6 +50,26 @@ def deviation(grads, base):
             "all_tensors_full_frobenius": top(fro_all)}
 
 
+FAMILIES = ("attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight", "attn.rel_pos_h", "attn.rel_pos_w")
+
+
+def per_block(grads, base, depth):
+    """Round 6: per transformer block and weight family, the sampled rel-max AND the whole-tensor relative
+    Frobenius error -- does the deviation grow towards block 0 (rounding accumulated along the residual chain) or is it flat (the
+    weight-gradient GEMM's own bf16 operands)?  -> {family: {"sampled_relmax": [depth], "frobenius": [depth]}}"""
+    out = {}
+    for fam in FAMILIES:
+        sm, fr = [], []
+        for i in range(depth):
+            n = "blocks.%d.%s" % (i, fam)
+            a = grads[n].detach().float().cpu().reshape(-1)
+            b = base[n].detach().float().cpu().reshape(-1)
+            sm.append(G.rel_err(a[::STRIDE], b[::STRIDE]) if b.numel() > SMALL else G.rel_err(a, b))
+            fr.append(G.rel_fro(a, b))
+        out[fam] = {"sampled_relmax": sm, "frobenius": fr}
+    return out
+
+
 def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "grad_yardstick.json")
     assert torch.cuda.is_available() and ref_import.reference_available()
@@ -93,6 +113,8 @@ def main():
         d["loss_rel"] = abs(l16 - l32) / abs(l32)
         d["pred_rel_frobenius"] = G.rel_fro(p16, p32)
         d["pred_rel_max"] = G.rel_err(p16, p32)
+        if name == "bf16":
+            d["per_block"] = per_block(g16, g32, cfg.depth)
         res["reference_%s_autocast_vs_reference_fp32" % name] = d
     del rm
     torch.cuda.empty_cache()
@@ -117,6 +139,7 @@ def main():
     d["loss_rel"] = abs(float(loss) - l32) / abs(l32)
     d["pred_rel_frobenius"] = G.rel_fro(pred.detach().float().cpu(), p32)
     d["pred_rel_max"] = G.rel_err(pred.detach().float().cpu(), p32)
+    d["per_block"] = per_block(gh, g32, cfg.depth)
     res["hip_bf16_build_vs_reference_fp32"] = d
     try:
         from painter_amd._lib import LIB_PATH
@@ -127,7 +150,14 @@ def main():
     os.makedirs(os.path.dirname(out_path), exist_ok=True)
     with open(out_path, "w") as f:
         json.dump(res, f, indent=1)
-    print(json.dumps(res, indent=1))
+    print(json.dumps({k: v for k, v in res.items()}, indent=1)[:6000])
+    # the per-block table, reference-bf16 next to HIP-bf16 (whole-tensor relative Frobenius error, then sampled rel-max)
+    rb, hb = res["reference_bf16_autocast_vs_reference_fp32"]["per_block"], res["hip_bf16_build_vs_reference_fp32"]["per_block"]
+    for metric in ("frobenius", "sampled_relmax"):
+        print("\n%s per block: reference bf16 autocast | HIP bf16 build (both against the reference's fp32 gradients)" % metric)
+        print("blk " + " ".join("%21s" % f.split(".", 1)[1] for f in FAMILIES))
+        for i in range(cfg.depth):
+            print("%3d " % i + " ".join("%10.2e|%10.2e" % (rb[f][metric][i], hb[f][metric][i]) for f in FAMILIES))
 
 
 if __name__ == "__main__":
