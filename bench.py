@@ -32,10 +32,13 @@ all-reduce (RCCL, bucketed, overlapped with backward) is inside the step.  Print
   secondary    = the other single-GPU BASELINE configurations, measured AFTER the headline number and outside its timed region (N = 1):
                  seggpt_n32 = BASELINE configs[3] (seggpt_vit_large_patch16_input896x448, 32 prompts over one query, feature ensemble,
                  forward captured in a hipGraph, 5 replays), vit_huge = configs[4]'s per-GPU half (ViT-H/14 bf16, B = 4, 3 steps).
-  gradsync_variants (N > 1, under `extra`) = the same K steps timed back to back under three gradient-exchange arrangements --
+  gradsync_variants (N > 1, under `extra`) = the same K steps timed back to back under four gradient-exchange arrangements --
                  per-block RCCL messages from inside the backward (GradSync, the default), four coarse coalesced launches (GradSync
-                 mode "coarse"), the plain DistributedDataParallel wrapper (the reference's arrangement: no overlap with OUR backward,
-                 the floor) -- `value` is the best of them and `config.grad_allreduce` says which.
+                 mode "coarse"), the per-block messages as reduce-scatter + all-gather pairs (mode "rs_ag": the all-peer pattern over the
+                 seven xGMI links), the plain DistributedDataParallel wrapper (the reference's arrangement: no overlap with OUR backward,
+                 the floor) -- `value` is the best of them and `config.grad_allreduce` says which.  Each carries `exposed_comm_ms` = its
+                 step time minus the step time of the same process with NO exchange (`extra.no_exchange_ms_per_step`), so the line
+                 explains its own scaling efficiency; `config.rccl_ranks` is asserted equal to N.
   reference_gpu = the same unmodified reference model on THIS GPU through PyTorch-ROCm eager (autocast bf16, and fp16 -- the reference's
                  literal torch.cuda.amp.autocast() -- beside it), B = 8, the bench model's parameters and batch, train forward+backward;
                  vs_reference_gpu = value / that.  A baseline leg outside every timed region of the headline number (N = 1 only).
@@ -560,8 +563,8 @@ def main():
     ap.add_argument("--no-reference-gpu", action="store_true", help="skip the reference-on-this-GPU leg (unmodified reference model, PyTorch eager)")
     ap.add_argument("--no-optimizer", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (SegGPT N = 32 hipGraph, ViT-H/14 B = 4) after the headline measurement")
-    ap.add_argument("--gradsync", default="all", choices=["all", "per_block", "coarse", "ddp"],
-                    help="N > 1: which gradient-exchange arrangement(s) to time (all = the three back to back, value = the best)")
+    ap.add_argument("--gradsync", default="all", choices=["all", "per_block", "coarse", "rs_ag", "ddp"],
+                    help="N > 1: which gradient-exchange arrangement(s) to time (all = the four back to back, value = the best)")
     ap.add_argument("--eval", action="store_true", help="eval mode (no DropPath)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo = DEBUG: run the N > 1 branch (relaunch, parameter broadcast, GradSync inside the backward, MAX-reduced timing) "
@@ -648,14 +651,22 @@ def main():
     if not distributed:
         dt, lossv = timed_region()
     else:
-        todo = ["per_block", "coarse", "ddp"] if args.gradsync == "all" else [args.gradsync]
+        assert n_ranks == args.gpus, (n_ranks, args.gpus)    # the group really has as many ranks as the line will claim (config.rccl_ranks)
+        todo = ["per_block", "coarse", "rs_ag", "ddp"] if args.gradsync == "all" else [args.gradsync]
         gs_errors = {}
+        # the same K steps with NO exchange at all (every rank differentiates its own batch; nothing is updated, so replicas stay equal):
+        # what an arrangement adds to this is its EXPOSED communication (extra.exposed_comm_ms) -- the line explains its own efficiency
+        model.grad_sync = None
+        no_exchange_s, _ = timed_region()
         for name in [v for v in todo if v != "ddp"]:
-            try:                                            # one arrangement failing at the Python level (the same on every rank) leaves the others
+            # one arrangement failing at the Python level leaves the others (the failure is the same on every rank: same code, same
+            # arguments).  RuntimeError included: that is what torch.distributed / RCCL raise for an unsupported argument --
+            # raised at call time, before anything of that call is enqueued; per_block (plain all_reduce, the most basic call) runs first.
+            try:
                 model.grad_sync = parallel.GradSync(mode=name)
                 d_, l_ = timed_region()
                 variants[name] = {"seconds": d_, "loss": l_, "collective_launches_per_step": model.grad_sync.launches // (args.steps + args.warmup)}
-            except (TypeError, ValueError, AttributeError, NotImplementedError) as e:
+            except Exception as e:
                 gs_errors[name] = "%s: %s" % (type(e).__name__, str(e)[:200])
         if gs_errors and not variants and "ddp" not in todo:
             raise RuntimeError("every gradient-exchange arrangement failed: %r" % gs_errors)
@@ -711,6 +722,7 @@ def main():
         for v in variants.values():
             v["value"] = round(n_ranks * args.batch * args.steps / v["seconds"], 3)
             v["ms_per_step"] = round(v["seconds"] / args.steps * 1e3, 3)
+            v["exposed_comm_ms"] = round((v["seconds"] - no_exchange_s) / args.steps * 1e3, 3)      # against the same process's step without any exchange
             v["seconds"] = round(v["seconds"], 4)
 
     # ---- separate profiled pass (never compare a profiled arm with an un-profiled one: `value` above is un-instrumented)
@@ -800,6 +812,7 @@ def main():
                        "taps": list(cfg.taps),
                        "grad_allreduce": {"per_block": "RCCL, one message per weight matrix + one flat message per block, started from inside the backward (GradSync)",
                                           "coarse": "RCCL, four coalesced launches of ~400 MB from inside the backward (GradSync mode coarse)",
+                                          "rs_ag": "RCCL, per_block's messages as reduce_scatter_tensor + all_gather_into_tensor (all-peer pattern over the seven xGMI links), started from inside the backward (GradSync)",
                                           "ddp": "torch DistributedDataParallel wrapper (the reference's arrangement; no overlap with the HIP backward)"}.get(arrangement, "n/a")},
             "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "definition": "images/s/GPU x %.3f TFLOP (attention + MLP blocks, fwd+bwd; SURVEY.md 8d) / dense bf16 MFMA peak" % (spec["blocks"] / 1e12),
@@ -815,7 +828,10 @@ def main():
             "build": {"git_head": _git_head(), "lib_sha16": _lib_sha16()},
         }
         if variants:
-            out["extra"] = dict(out["extra"] or {}, gradsync_variants=variants, gradsync_chosen=arrangement)
+            out["extra"] = dict(out["extra"] or {}, gradsync_variants=variants, gradsync_chosen=arrangement,
+                                no_exchange_ms_per_step=round(no_exchange_s / args.steps * 1e3, 3),
+                                exposed_comm_ms=variants[arrangement]["exposed_comm_ms"],
+                                sustained_arrangement=(sustained or {}).get("gradsync"))
             if ddp_error:
                 out["extra"]["gradsync_ddp_error"] = ddp_error
             if gs_errors:

@@ -44,11 +44,13 @@ int pa_abi_version(void);
  * 1 drop that kernel's epilogue stores (never set by the product path); 2 = tile order of that kernel: 0 blocked 4 x 8 patches per XCD and, for
  * split-K launches, one contiguous (split, tile) run per XCD (default), 1 plain row-major, 2 blocked with split = blockIdx.y (before round 5); 3 = TUNING, set by the engine: target number of workgroups
  * of the weight-gradient GEMM (0 = 256, the whole chip; 64 when the weight gradients run on a side stream); 4 = row-tile height of the un-split bf16
- * GEMMs: 0 by rule (224 rows where that fills the last round of workgroups better), 1 always 256, 2 224 wherever possible; 5 = LayerNorm backward:
- * 0 rows split over the workgroup's waves wherever D >= 1024 (default), 1 one wave per row everywhere (the kernel of rounds 1 - 4); 6 = K splits of the
+ * GEMMs: 0 by rule (224 rows where that fills the last round of workgroups better), 1 always 256, 2 224 wherever possible; 5 = (G256_ILV_AB experiment
+ * builds only) 1 + the DMA-placement schedule of that kernel; 6 = K splits of the
  * rel-pos table-gradient GEMM; 7 = rel-pos table gradient inside the generation-3 dQ kernel: 0 default (on), 1 off, 2 on (tests);
  * 8 = generation-3 attention: workgroups with idle waves dispatched last: 0 default (off since round 5), 1 off, 2 on;
- * 9 = tests: cap on the workgroups of the conv3x3 weight-gradient kernel (0 = 512), so that small images make a workgroup walk many tiles. */
+ * 9 = tests: cap on the workgroups of the conv3x3 weight-gradient kernel (0 = 512), so that small images make a workgroup walk many tiles;
+ * 10 = LayerNorm backward: 0 rows split over the workgroup's waves wherever D >= 1024 (default), 1 one wave per row everywhere (the kernel of
+ * rounds 1 - 4) -- index 5 until round 5, where it collided with the ILV override; 11 .. 15 = round-6 experiment knobs (csrc/common.h). */
 int pa_debug_set(int which, int value);
 int pa_debug_get(int which);      /* the value last set (-1: no such knob) -- callers that change a knob temporarily restore what they found */
 
@@ -130,7 +132,12 @@ int pa_attn_fwd(int dtype, const void* qkv, int64_t ldq, const void* rcat, void*
  *            dG is not written, and pa_attn_bwd_relpos_reduce() sums the partials into drcat in a fixed order (deterministic)
  *   aux    : scratch of pa_attn_bwd_aux_bytes()
  *   tables : what pa_attn_fwd wrote (NULL: the backward recomputes the bias tables itself, generation-2 kernels); since ABI 5 the forward
- *            also writes the log-sum-exp fields of the tiles, the backward adds the Delta field
+ *            also writes the log-sum-exp fields of the tiles, the backward adds the Delta field.
+ *            CONTRACT: the tiles must come from pa_attn_fwd of THIS library version (ABI >= 5) on the SAME qkv / rcat / scale -- the dKV kernel
+ *            contracts the bf16 bias entries and the -lse / scale hi + lo fields it finds there and nothing checks their origin; tiles
+ *            built or copied another way (the ABI-4 contract: a prep launch filled every field) give silently wrong dK / dV.  Callers
+ *            that cannot guarantee it pass tables = NULL (generation 2 recomputes everything) or run pa_attn_bwd_prep, which rewrites the
+ *            lse and Delta fields from `lse` / `out` / `dout` (the bias entries still have to be the forward's).
  *   out / ldo : the forward's output O (T [batch*L, heads*hd]) or NULL.  Given with delta = NULL where pa_attn_bwd_prep_ok(): the dQ kernel
  *            computes Delta = rowsum(dO o O) itself -- no pa_attn_bwd_delta / pa_attn_bwd_prep launch at all (ABI 5; the engine's route)
  *   rcatT  : T [hd, NRP] from pa_relpos_pack_t

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NT, STAGES == 1 ? 4 : 2) void fwd_kernel(const bf16
             lse[(size_t)bh * L + q] = lse_q;
             if (tables != nullptr) {      // -lse / scale as the bf16 hi + lo pair the dKV kernel contracts (rows Hp, Hp + 1 of the kh part): round 5,
                 unsigned char* tt = tables + ((size_t)bh * ntile + qt) * ttile_bytes(Hp);      // was a separate launch in front of the backward
-                const float x = -lse_q / scale;
+                const float x = -lse_q * (1.f / scale);      // the same multiply the prep kernels use: the "fused" and "launch" routes stay bit-comparable for any scale
                 const bf16 hi = (bf16)x;
                 *reinterpret_cast<bf16*>(tt + 2048 + Hp * 64 + ql * 2) = hi;
                 *reinterpret_cast<bf16*>(tt + 2048 + (Hp + 1) * 64 + ql * 2) = (bf16)(x - (float)hi);

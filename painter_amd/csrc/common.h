@@ -122,13 +122,16 @@ inline int g_attn3_fuse = 0;
 // pa_debug_set(8, v): 0 = default (light attention workgroups NOT dispatched last unless PA_ATTN_LIGHT_LAST=1; round 5), 1 = off, 2 = on
 inline int g_attn_light_last = 0;
 
-// pa_debug_set(5, v): LayerNorm backward variant: 0 = default (rows split over the 4 waves of a workgroup wherever D >= 1024), 1 = one wave per
+// pa_debug_set(10, v) (round 5 shared index 5 with gemm256's ILV schedule override): LayerNorm backward variant: 0 = default (rows split over the 4 waves of a workgroup wherever D >= 1024), 1 = one wave per
 // row everywhere (the kernel of rounds 1 - 4; still what narrow D runs)
 inline int g_ln_bwd_variant = 0;
 
 // pa_debug_set(9, n): tests only -- cap on the number of workgroups of the conv3x3 weight-gradient kernel (0 = the product's 512): with a small
 // cap every workgroup walks many tiles, through both ring phases and across column-strip boundaries, at test sizes
 inline int g_conv_wgrad_groups = 0;
+// pa_debug_set(11 .. 15, v): round-6 experiment knobs, read where they are named: [0] = 11 gemm256 tile patch per XCD (0 = default,
+// TR * 16 + TC otherwise), [1] = 12 mixed 224-row + 128-row tiles for the multi-round GEMMs (0 = default on, 1 = off), [2] = 13, [3] = 14, [4] = 15 free
+inline int g_misc_knob[5] = {0, 0, 0, 0, 0};
 
 // host-side launch counters of the attention entry points, by kernel family: [0..2] pa_attn_fwd on the generic (attn_fwd.hip) /
 // generation-2 (attn2.hip) / generation-3 (attn3.hip) kernels, [3..5] pa_attn_bwd likewise (pa_attn_launch_counts; the model-level tests

@@ -446,7 +446,7 @@ extern "C" int pa_linear_pixshuf(int dtype, const void* x, int64_t ldx, const vo
 // dx_colsum (optional): f32 [K] = column sums of dX as stored -- partial rows from the GEMM's epilogue on the bf16 fast path when the
 // GELU side input is given (workspace), a separate pa_colsum pass over dX otherwise
 extern "C" int64_t pa_linear_dgrad_workspace_bytes(int M, int K) {
-    const int64_t fast = (int64_t)2 * ((M + g256::BM_SHORT - 1) / g256::BM_SHORT) * K * sizeof(float);
+    const int64_t fast = (int64_t)2 * ((M + g256::BM_HALF - 1) / g256::BM_HALF) * K * sizeof(float);      // (an upper bound for every tile plan: all rows as half tiles)
     const int64_t slow = pa_colsum_workspace_bytes(M, K);
     return fast > slow ? fast : slow;
 }
@@ -497,8 +497,10 @@ static int wgrad_fast_splits(int M, int N, int K) {
     static const int env_target = [] { const char* v = getenv("PA_WGRAD_WGS"); return v ? atoi(v) : 0; }();
     int target = env_target > 0 ? env_target : (g256::g_dbg[3] > 0 ? g256::g_dbg[3] : 256);
     if (target < 16) target = 16;
-    int s = (target + 3 * tiles / 4) / tiles;          // (rounds up from x.25: ViT-H/14's 75-tile qkv gradient gets 2 splits = 150 workgroups at target 96, not 75 long ones;
-    if (s < 1) s = 1;                                   //  every ViT-L shape -- 16 / 48 / 64 tiles -- keeps the split count it had with round-half-up)
+    int s = (target + 3 * tiles / 4) / tiles;          // (rounds up from x.25: ViT-H/14's 75-tile qkv gradient gets 2 splits = 150 workgroups at target 96, not 75 long ones.
+    if (s < 1) s = 1;                                   //  At the side-stream target 96 every ViT-L shape -- 16 / 48 / 64 tiles -- keeps the count round-half-up gave it; at the
+                                                        //  stand-alone target 256 (one stream, bench.py's profiled pass) the 48-tile qkv gradient goes from 5 to 6 splits, so the
+                                                        //  profiled gemm256_wgrad / slab figures from round 5 on are not like-for-like with profiles/r0[1-4]_*.csv)
     const int ktiles = M / 64;
     if (s > ktiles / 4) s = ktiles / 4 > 0 ? ktiles / 4 : 1;
     return g256::splits_used(M, s);
@@ -548,20 +550,25 @@ extern "C" int pa_linear_wgrad(int dtype, const void* dy, int64_t lddy, const vo
 }
 
 extern "C" int pa_abi_version(void) { return PA_ABI_VERSION; }
+// knobs: 0-4 gemm256 (g256::g_dbg), 5 the G256_ILV_AB schedule override (experiment builds), 6 rel-pos splits, 7 fused rel-pos gradient,
+// 8 light attention workgroups last, 9 conv3x3 weight-gradient groups, 10 LayerNorm-backward variant (round 5 shared index 5 with the ILV
+// override: tools that swept one silently switched the other)
 extern "C" int pa_debug_get(int which) {
-    if (which < 0 || which > 9) return -1;
+    if (which < 0 || which > 15) return -1;
     if (which == 9) return g_conv_wgrad_groups;
-    if (which == 5) return g_ln_bwd_variant;
+    if (which == 10) return g_ln_bwd_variant;
+    if (which > 10) return g_misc_knob[which - 11];
     if (which == 6) return g_relpos_splits;
     if (which == 7) return g_attn3_fuse;
     if (which == 8) return g_attn_light_last;
     return g256::g_dbg[which];
 }
 extern "C" int pa_debug_set(int which, int value) {
-    if (which < 0 || which > 9) return (int)hipErrorInvalidValue;
+    if (which < 0 || which > 15) return (int)hipErrorInvalidValue;
     if (which < 8) g256::g_dbg[which] = value;
     if (which == 9) g_conv_wgrad_groups = value;
-    if (which == 5) g_ln_bwd_variant = value;
+    if (which == 10) g_ln_bwd_variant = value;
+    if (which > 10) g_misc_knob[which - 11] = value;
     if (which == 6) g_relpos_splits = value;
     if (which == 7) g_attn3_fuse = value;
     if (which == 8) g_attn_light_last = value;

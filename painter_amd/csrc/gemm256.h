@@ -143,11 +143,27 @@ template <class Epi> struct epi_hi_off<Epi, std::void_t<decltype(Epi::HI_OFF)>> 
 // stored -- 14 instead of 16 MFMAs per k-step on every SIMD (each SIMD hosts one wave of either row).  Same ascending K order per
 // output element: bit-identical results.  Only for a K-major A operand (forward and data-gradient GEMMs).
 constexpr int BM_SHORT = 224;
-template <bool AMM, bool BMM, int ILV, class Epi, bool SHORT = false>
+// MIXED (round 6): full-height tiles for a whole number of rounds of 256 workgroups, then HALF tiles of 128 rows for the rest of the rows.
+// R = 12544 = 2^8 * 7^2 rows leave every multi-round GEMM of the ViT-L blocks with a last round that is half empty (fc1: 896 tiles of 224
+// rows = 3.5 rounds, run as 4; qkv: 2.6 as 3; every uniform tiling was enumerated in round 3 -- docs/HISTORY.md 4.5).  A half tile keeps the
+// workgroup and the 256-row LDS image, but runs its OWN loop (one top-level, workgroup-uniform branch; the full-tile loop is untouched):
+// wave row r computes rows 64 r .. 64 r + 63 of the tile -- operand unit a_r, which it reads where wave row 0 reads its rows -- against both
+// column halves: the MFMA segments of phases 0 / 1 of the full schedule, on 64 accumulator registers.  Phases 2 / 3 have no MFMAs; they
+// re-stage the four units of the stage just read for the tile after next (all DMA of a K tile sits there, 8 pieces ahead of its first read:
+// a deeper look-ahead than the full loop's).  A K tile so takes ~ 0.6 of a full tile's time for half its MFMAs.  (The DMA of the lower 128
+// image rows is wasted on the next tile's rows: 25 % more L2 reads on 6 % of the tiles.)  fc1: 48 x 16 full tiles = 3 rounds exactly +
+// 2 x 16 half tiles on idle CUs instead of a fourth round.  Same ascending K order per output element: bit-identical results.
+// The first attempt predicated the MFMA segments of ONE loop per wave row (run-time branches inside the K loop): hipcc then drains vmcnt /
+// lgkmcnt at every join -- the LDS-DMA and the asm fragment reads are opaque to it -- and the FULL tiles ran 22 - 28 % slower
+// (profiles/r06_ab_mixed_tiles_first_attempt.log).  No branch may sit inside this kernel's K loop.
+// Tiles [0, nfull * tiles_n) are full (BMR rows), the rest are half tiles starting at row nfull * BMR; only for a K-major A operand, no K split.
+constexpr int BM_HALF = 128;
+template <bool AMM, bool BMM, int ILV, class Epi, bool SHORT = false, bool MIXED = false>
 __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag, uint32_t lda, const bf16* __restrict__ Bg,
                                                       uint32_t ldb, Epi epi, int M, int N, int ktiles, int ktiles_per_split,
-                                                      int tiles_n, int stagger, int order) {
+                                                      int tiles_n, int stagger, int order, int nfull, int patch) {
     static_assert(!(SHORT && AMM), "the 224-row tile is built for a K-major A operand");
+    static_assert(!(MIXED && (AMM || SHORT)), "half tiles are built for a K-major A operand and 256-row full tiles");
     constexpr int BMR = SHORT ? BM_SHORT : BM;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -163,7 +179,10 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
 
     // XCD-aware tile order: workgroup b runs on XCD b % 8; give each XCD a contiguous run of tiles (j fastest) so that the
     // tiles sharing an A row panel hit the same L2.
-    const int nwg = gridDim.x, bid = blockIdx.x;
+    // (MIXED: the full tiles and the half tiles are two regions of the grid, each ordered on its own)
+    const bool htile = MIXED && (int)blockIdx.x >= nfull * tiles_n;
+    const int nwg = MIXED ? (htile ? (int)gridDim.x - nfull * tiles_n : nfull * tiles_n) : (int)gridDim.x;
+    const int bid = htile ? (int)blockIdx.x - nfull * tiles_n : (int)blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
     int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     int split = blockIdx.y;
@@ -185,8 +204,8 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
     // per launch; the weight matrix alone is twice the L2).  g_dbg[2] = 1 restores the plain row-major order (A/B).
     int tm, tn;
     if (order != 1) {
-        constexpr int TR = 4, TC = 8;
-        const int tiles_m = (M + BMR - 1) / BMR;
+        const int TR = patch > 0 ? patch / 100 : 4, TC = patch > 0 ? patch % 100 : 8;      // patch (PA_G256_PATCH / pa_debug_set(11, TR * 100 + TC)): experiments
+        const int tiles_m = MIXED ? (htile ? (M - nfull * BMR + BM_HALF - 1) / BM_HALF : nfull) : (M + BMR - 1) / BMR;
         const int per_group = TR * tiles_n;
         const int gm = tile / per_group, rem = tile - gm * per_group;
         const int rg = min(TR, tiles_m - gm * TR);                   // row panels in this (possibly last, shorter) group
@@ -204,7 +223,7 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
         tm = tile / tiles_n;
         tn = tile - tm * tiles_n;
     }
-    const int i0 = tm * BMR, j0 = tn * BN;
+    const int i0 = htile ? nfull * BMR + tm * BM_HALF : tm * BMR, j0 = tn * BN;
     const bool blk3 = !(SHORT && wr == 1);          // does this wave own the fourth 32-row block of its 128 rows?  (wave-uniform)
     const int kt0 = split * ktiles_per_split;
     const int nt = min(ktiles - kt0, ktiles_per_split);
@@ -244,7 +263,8 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
         const int i = lane & 15, half = (lane >> 4) & 1;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if constexpr (!AMM) ra[ks] = (uint32_t)((wr * 64 + lr) * 128 + ((t << 4) ^ (ks << 5)));
+            // (half tile: wave row r reads unit a_r -- 32 KB further on -- at the rows wave row 0 owns in it)
+            if constexpr (!AMM) ra[ks] = (uint32_t)((htile ? wr * 32768 + lr * 128 : (wr * 64 + lr) * 128) + ((t << 4) ^ (ks << 5)));
             if constexpr (!BMM) rb[ks] = (uint32_t)(65536 + (wc * 32 + lr) * 128 + ((t << 4) ^ (ks << 5)));
         }
         if constexpr (AMM) {
@@ -356,22 +376,80 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    // ---- prologue: tile 0 entirely, plus a0/b0 of tile 1   (nt is even and >= 2: see launch())
-    stage_a(0, 0, 0);
-    stage_b(0, 0, 0);
-    stage_b(1, 0, 0);
-    stage_a(1, 0, 0);
-    stage_a(0, 1, 1);
-    stage_b(0, 1, 1);
-    wait_vm<8>();
-    bar();
-    if (wr == 1) bar();   // lower wave row runs half a phase behind
+    // half tile (MIXED): a K tile is TWO phases -- the MFMA segments of phases 0 / 1 of the schedule above, on unit a_wr -- with ONE barrier
+    // each, all eight waves in step (no half-phase offset between the wave rows: with two phases per tile the offset would need the DMA
+    // waited two barriers ahead of its first read, i.e. inside the interval it is issued in).  The DMA of the NEXT tile goes into the other
+    // stage -- whose last reads completed in front of the previous barrier -- between this tile's MFMAs: four pieces in phase 0 (the
+    // upper 8 KB halves of a0 / a1 -- the lower halves hold image rows 128..255, which a half tile never reads -- and b0), two in phase 1
+    // (b1).  Counted waits at the END of a phase, in front of its barrier: phase 0 leaves its own four pieces in flight (b1 of this tile has
+    // landed: read right behind the barrier), phase 1 its own two (a0, a1, b0 of the next tile have landed).
+    // (The first version kept the four-phase frame and re-staged in two MFMA-free phases: eight bare DMA issues cost as much as the MFMA
+    // segments they no longer hid behind -- a half round took 0.85 of a full round: profiles/r06_ab_mixed_tiles_half_loop.log.)
+    auto half_body = [&](auto stage_c, int T) {
+        constexpr int S = decltype(stage_c)::value;
+        const int t1 = min(T + 1, nt - 1);
+#define G256_HMMA(KS, NC) \
+        acc[0][NC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((NC ? fb1 : fb0).template k<KS>(), fa0.template k<KS>(), acc[0][NC], 0, 0, 0); \
+        acc[1][NC] = __builtin_amdgcn_mfma_f32_32x32x16_bf16((NC ? fb1 : fb0).template k<KS>(), fa1.template k<KS>(), acc[1][NC], 0, 0, 0);
+#define G256_HDMA(X) __builtin_amdgcn_sched_barrier(0); X; __builtin_amdgcn_sched_barrier(0);
+        // ---- phase 0: a_wr, b0 of stage S; stage the next tile's a0, a1 (upper halves), b0 into stage S ^ 1
+        fa0.template read<unit_off(false, 0, S)>(ra, 0);
+        fa1.template read<unit_off(false, 0, S) + 4096>(ra, 1);
+        fb0.template read<unit_off(true, 0, S) - 65536>(rb, 0);
+        lwait();
+        __builtin_amdgcn_s_setprio(1);
+        G256_HMMA(0, 0) G256_HDMA(piece_a(0, S ^ 1, t1, 0))
+        G256_HMMA(1, 0) G256_HDMA(piece_a(1, S ^ 1, t1, 0))
+        G256_HMMA(2, 0) G256_HDMA(piece_b(0, S ^ 1, t1, 0))
+        G256_HMMA(3, 0) G256_HDMA(piece_b(0, S ^ 1, t1, 1))
+        __builtin_amdgcn_s_setprio(0);
+        wait_vm<4>();
+        bar();
+        // ---- phase 1: b1 of stage S; stage the next tile's b1
+        fb1.template read<unit_off(true, 1, S) - 65536>(rb, 0);
+        lwait();
+        __builtin_amdgcn_s_setprio(1);
+        G256_HMMA(0, 1) G256_HDMA(piece_b(1, S ^ 1, t1, 0))
+        G256_HMMA(1, 1) G256_HMMA(2, 1) G256_HDMA(piece_b(1, S ^ 1, t1, 1))
+        G256_HMMA(3, 1)
+        __builtin_amdgcn_s_setprio(0);
+        wait_vm<2>();
+        bar();
+#undef G256_HMMA
+#undef G256_HDMA
+    };
 
-    for (int T = 0; T < nt; T += 2) {
-        tile_body(I0{}, T);
-        tile_body(I1{}, T + 1);
+    bool ran_half = false;
+    if constexpr (MIXED) {
+        if (htile) {                       // workgroup-uniform, outside every loop
+            ran_half = true;
+            piece_a(0, 0, 0, 0); piece_a(1, 0, 0, 0); stage_b(0, 0, 0); stage_b(1, 0, 0);      // tile 0 into stage 0
+            wait_vm<0>();
+            bar();
+            for (int T = 0; T < nt; T += 2) {
+                half_body(I0{}, T);
+                half_body(I1{}, T + 1);
+            }
+        }
     }
-    if (wr == 0) bar();
+    if (!ran_half) {
+        // ---- prologue: tile 0 entirely, plus a0/b0 of tile 1   (nt is even and >= 2: see launch())
+        stage_a(0, 0, 0);
+        stage_b(0, 0, 0);
+        stage_b(1, 0, 0);
+        stage_a(1, 0, 0);
+        stage_a(0, 1, 1);
+        stage_b(0, 1, 1);
+        wait_vm<8>();
+        bar();
+        if (wr == 1) bar();   // lower wave row runs half a phase behind
+
+        for (int T = 0; T < nt; T += 2) {
+            tile_body(I0{}, T);
+            tile_body(I1{}, T + 1);
+        }
+    }
+    if (wr == 0 && !ran_half) bar();       // (the full loop's half-phase offset between the wave rows; the half-tile loop runs in step)
     wait_vm<0>();          // the clamped tail DMAs must have landed before this workgroup's LDS is handed on
 
     // ---- epilogue.  A lane owns one output row of each 32x32 block; storing from there would touch 32 cache lines per
@@ -390,21 +468,23 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
         const int lr = lane & 31, g = lane >> 5, rrow = lane >> 3, c0 = (lane & 7) * (HO == 4 ? 8 : 4);
         const int jcol = j0 + wc * 64 + c0;
         const typename Epi::Col col = epi.col(jcol);
+        const int rbase = i0 + wr * (htile ? 64 : 128);         // first tile row of this wave
         float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
+        for (int hf = 0; hf < 2; ++hf) {
+            if (MIXED && htile && hf != 0) continue;           // half tile: a wave holds two 32-row blocks (accumulator blocks 0, 1): rows 64 wr .. 64 wr + 63
             typename Epi::Row rows[2][4];
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
-                    const int mb = half * 2 + m2;
+                    const int mb = hf * 2 + m2;
                     if (SHORT && mb == 3 && !blk3) continue;
-                    rows[m2][st] = epi.row(i0 + wr * 128 + (mb >> 1) * 64 + (mb & 1) * 32 + st * 8 + rrow, jcol);
+                    rows[m2][st] = epi.row(rbase + (mb >> 1) * 64 + (mb & 1) * 32 + st * 8 + rrow, jcol);
                 }
 #pragma unroll
             for (int m2 = 0; m2 < 2; ++m2) {
-                const int mb = half * 2 + m2;
+                const int mb = hf * 2 + m2;
                 if (SHORT && mb == 3 && !blk3) continue;
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
@@ -414,7 +494,7 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
                         *reinterpret_cast<float4*>(stg + lr * 68 + nb * 32 + q * 8 + g * 4) =
                             make_float4(c[q * 4 + 0], c[q * 4 + 1], c[q * 4 + 2], c[q * 4 + 3]);
                     }
-                const int ib = i0 + wr * 128 + (mb >> 1) * 64 + (mb & 1) * 32;
+                const int ib = rbase + (mb >> 1) * 64 + (mb & 1) * 32;
 #pragma unroll
                 for (int st = 0; st < 4; ++st) {
                     const int r = st * 8 + rrow;
@@ -436,7 +516,7 @@ __global__ __launch_bounds__(NT) void gemm256_kernel(const bf16* __restrict__ Ag
                 v += lane_xor32(v);
                 cs[e] = v;
             }
-            if (lane < 8) epi.colsum_out(tm * 2 + wr, jcol, cs);
+            if (lane < 8) epi.colsum_out((htile ? nfull + tm : tm) * 2 + wr, jcol, cs);      // one partial row per (row tile, wave row), full tiles first
         }
     }
 }
@@ -445,8 +525,8 @@ static inline int per_split(int ktiles, int nsplit) {
     int per = (ktiles + nsplit - 1) / nsplit;
     return per + (per & 1);
 }
-template <bool AMM, bool BMM, int ILV, bool SHORT, class Epi>
-static int launch_ilv(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit, hipStream_t st);
+template <bool AMM, bool BMM, int ILV, bool SHORT, class Epi, bool MIXED = false>
+static int launch_ilv(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit, hipStream_t st, int nfull = 0);
 #ifndef G256_ILV_DEFAULT
 #define G256_ILV_DEFAULT 2     // round 3 (tools/gemm_ilv_ab.py, MI355X): 2 is 4-15 % faster than 0 on the forward GEMMs, 4-6 % on the data gradients,
 #endif                         // 2 % on the weight gradients, bit-identical results; 1 = 0.  In the training step the gain shrinks to ~1 % (DVFS)
@@ -463,11 +543,40 @@ static inline bool use_short(int M, int N, int nsplit, bool amm) {
     const long r256 = (t256 + 255) / 256 * 100, r224 = (t224 + 255) / 256 * cost;
     return r224 < r256;
 }
+// Tile plan of an un-split launch with a K-major A operand (round 6): uniform 256-row tiles, uniform 224-row tiles, or MIXED = `nfull` rows of
+// 256-row tiles filling whole rounds of 256 workgroups + half tiles (128 rows) for the remaining rows.  Costs in percent of a 256-row round,
+// measured (tools/gemm_mixed_probe.py, profiles/r06_ab_mixed_tiles_half_loop.log): a 224-row round 97 -- 14 of 16 MFMAs, the whole load segment
+// and every barrier (PA_G256_SHORT_COST; the choice between the two uniform tilings keeps round 4's 92) --, a half-tile round 75
+// (PA_G256_HALF_COST): half the MFMAs on 3/4 of the LDS-DMA, and the DMA issues are what the loop is short of.  pa_debug_set(12, v): 0 = this
+// rule, 1 = no mixed plans (the round-5 behaviour), 2 = mixed with pa_debug_set(14, nfull) full rows (diagnostics).
+struct TilePlan { bool is_short, mixed; int nfull; };
+static inline TilePlan tile_plan(int M, int N, int nsplit, bool amm) {
+    TilePlan p{use_short(M, N, nsplit, amm), false, 0};
+    if (amm || nsplit != 1 || M < 2 * BM || g_misc_knob[1] == 1 || g_dbg[4] != 0) return p;
+    if (g_misc_knob[1] == 2 && g_misc_knob[3] > 0 && (long)g_misc_knob[3] * BM < M) return TilePlan{false, true, g_misc_knob[3]};      // diagnostics (tools/gemm_mixed_probe.py): pa_debug_set(12, 2) + pa_debug_set(14, nfull)
+    static const int cs = [] { const char* v = getenv("PA_G256_SHORT_COST"); return v ? atoi(v) : 97; }();
+    static const int ch = [] { const char* v = getenv("PA_G256_HALF_COST"); return v ? atoi(v) : 75; }();
+    const int tn = (N + BN - 1) / BN;
+    auto rounds = [](long t) { return (t + 255) / 256; };
+    long best = p.is_short ? rounds((long)((M + BM_SHORT - 1) / BM_SHORT) * tn) * cs : rounds((long)((M + BM - 1) / BM) * tn) * 100;
+    // (only 256-row full tiles; as many whole rounds of them as the rows allow, i.e. as few half tiles as possible: `<=` below)
+    for (int r = 1; r <= 64; ++r) {
+        const int nf = (int)((long)r * 256 / tn);
+        if (nf < 1) continue;
+        if ((long)nf * BM >= M) break;                                  // covered by full tiles alone: the uniform plans above
+        const long nh = (M - (long)nf * BM + BM_HALF - 1) / BM_HALF;
+        const long c = (long)r * 100 + rounds(nh * tn) * ch;
+        if (c <= best - 5) { best = c + 5; p = TilePlan{false, true, nf}; }      // at least 5 % of a round better than what it replaces; later r (more full rows) wins ties
+    }
+    return p;
+}
 template <bool AMM, bool BMM, class Epi>
 static int launch(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit,
                   hipStream_t st) {
     if constexpr (!AMM) {
-        if (use_short(M, N, nsplit, AMM)) return launch_ilv<AMM, BMM, G256_ILV_DEFAULT, true>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
+        const TilePlan tp = tile_plan(M, N, nsplit, AMM);
+        if (tp.mixed) return launch_ilv<AMM, BMM, G256_ILV_DEFAULT, false, Epi, true>(A, lda, B, ldb, epi, M, N, K, nsplit, st, tp.nfull);
+        if (tp.is_short) return launch_ilv<AMM, BMM, G256_ILV_DEFAULT, true>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
     }
 #ifdef G256_ILV_AB       // experiment build: all three schedules in one library, pa_debug_set(5, 1 + ILV) picks one at run time
     static const int env_ilv = [] { const char* v = getenv("PA_G256_ILV"); return v ? atoi(v) : G256_ILV_DEFAULT; }();
@@ -479,9 +588,9 @@ static int launch(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi,
     return launch_ilv<AMM, BMM, G256_ILV_DEFAULT, false>(A, lda, B, ldb, epi, M, N, K, nsplit, st);
 #endif
 }
-template <bool AMM, bool BMM, int ILV, bool SHORT, class Epi>
-static int launch_ilv(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit, hipStream_t st) {
-    auto kern = gemm256_kernel<AMM, BMM, ILV, Epi, SHORT>;
+template <bool AMM, bool BMM, int ILV, bool SHORT, class Epi, bool MIXED>
+static int launch_ilv(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi epi, int M, int N, int K, int nsplit, hipStream_t st, int nfull) {
+    auto kern = gemm256_kernel<AMM, BMM, ILV, Epi, SHORT, MIXED>;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -489,18 +598,23 @@ static int launch_ilv(const bf16* A, size_t lda, const bf16* B, size_t ldb, Epi 
         attr_done = true;
     }
     constexpr int BMR = SHORT ? BM_SHORT : BM;
-    const int tiles_m = (M + BMR - 1) / BMR, tiles_n = (N + BN - 1) / BN;
+    static const int env_patch = [] { const char* v = getenv("PA_G256_PATCH"); return v ? atoi(v) : 0; }();
+    const int tiles_n = (N + BN - 1) / BN;
+    const int tiles_m = MIXED ? nfull + (M - nfull * BMR + BM_HALF - 1) / BM_HALF : (M + BMR - 1) / BMR;
     const int ktiles = K / BK;
     const int per = per_split(ktiles, nsplit);
     const int splits = (ktiles + per - 1) / per;      // every split gets an even number (>= 2) of tiles
     if (g_dbg[1]) epi.M = 0;
     PA_LAUNCH(kern, dim3(tiles_m * tiles_n, splits), dim3(NT), LDS_BYTES, st, A, (uint32_t)lda, B, (uint32_t)ldb, epi, M, N,
-              ktiles, per, tiles_n, g_dbg[0], g_dbg[2]);
+              ktiles, per, tiles_n, g_dbg[0], g_dbg[2], nfull, g_misc_knob[0] > 0 ? g_misc_knob[0] : env_patch);
     return (int)hipGetLastError();
 }
 // row tiles of the launch launch<AMM = false>(...) makes for this shape (partial rows of a column-sum epilogue = 2 x this)
 static inline int row_tiles_used(int M, int N, int nsplit) {
-    return use_short(M, N, nsplit, false) ? (M + BM_SHORT - 1) / BM_SHORT : (M + BM - 1) / BM;
+    const TilePlan tp = tile_plan(M, N, nsplit, false);
+    const int bm = tp.is_short ? BM_SHORT : BM;
+    if (tp.mixed) return tp.nfull + (M - tp.nfull * bm + BM_HALF - 1) / BM_HALF;
+    return (M + bm - 1) / bm;
 }
 // shapes the kernel accepts; everything else stays on the generic engine (gemm_engine.h)
 static inline bool ok(int M, int N, int K, bool amm, bool bmm, size_t lda, size_t ldb) {

@@ -333,6 +333,7 @@ static int lnb_occ(int D) { return D <= 1024 ? 4 : 3; }
 static bool ln_bwd_rows_ok(int D) { return g_ln_bwd_variant != 1 && D >= 1024 && D <= 2048; }
 static int ln_bwd_blocks_rows(int R, int D) {
     const int nbatch = (R + LNB_RB - 1) / LNB_RB, cap = 256 * lnb_occ(D);
+    if (nbatch <= 0) return 0;                                  // an empty batch: no workgroups, no workspace (and no division by k = 0)
     const int k = (nbatch + cap - 1) / cap;                     // batches per workgroup
     return (nbatch + k - 1) / k;
 }
@@ -383,7 +384,7 @@ static int ln_bwd_t(const T* dy, int64_t lddy, const float* x, int64_t ldx, cons
 }
 // the reduction of pa_layernorm_bwd(dgamma_dbeta = NULL, ...)'s partial rows; with_colsum says whether that call was given a dxT_colsum
 extern "C" int pa_layernorm_bwd_reduce(const void* workspace, float* dgamma_dbeta, float* dxT_colsum, int with_colsum, int R, int D, hipStream_t st) {
-    if (workspace == nullptr || dgamma_dbeta == nullptr || (with_colsum && dxT_colsum == nullptr)) return (int)hipErrorInvalidValue;
+    if (R <= 0 || workspace == nullptr || dgamma_dbeta == nullptr || (with_colsum && dxT_colsum == nullptr)) return (int)hipErrorInvalidValue;
     const int np = with_colsum ? 3 : 2;
     return pa_slab_reduce2((const float*)workspace, dgamma_dbeta, dxT_colsum, 2 * D, np * D, ln_bwd_blocks(R, D), np * D, st);
 }
@@ -392,7 +393,7 @@ extern "C" int pa_layernorm_bwd(int dtype, const void* dy, int64_t lddy, const f
                                 const float* rstd, const float* gamma, const float* dres, float* dx, int64_t lddx,
                                 void* dxT, int64_t lddxT, const float* rowscale, int rows_per_sample,
                                 float* dgamma_dbeta, float* dxT_colsum, void* workspace, int R, int D, hipStream_t st) {
-    if (D % 4 || lddy % 4 || ldx % 4 || lddx % 4 || lddxT % 4) return (int)hipErrorInvalidValue;
+    if (R <= 0 || D % 4 || lddy % 4 || ldx % 4 || lddx % 4 || lddxT % 4) return (int)hipErrorInvalidValue;
     if (dtype == PA_BF16)
         return ln_bwd_t<bf16>((const bf16*)dy, lddy, x, ldx, mean, rstd, gamma, dres, dx, lddx, (bf16*)dxT, lddxT, rowscale,
                               rows_per_sample, dgamma_dbeta, dxT_colsum, (float*)workspace, R, D, st);

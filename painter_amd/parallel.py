@@ -39,10 +39,16 @@ class GradSync:
     collected gradients are exchanged as ONE coalesced collective (ncclGroupStart / End around the per-tensor all-reduces: one RCCL
     launch) whenever `bucket_bytes` have accumulated (default 400 MB -> four launches per ViT-L step: decoder_embed + blocks 23-21,
     blocks 20-13, 12-5, the rest) -- fewer, larger launches for the case where ~125 small ones cost more host time and RCCL channel
-    set-up than their finer overlap buys.  Same arithmetic, same result; bench.py --gpus N times both (and the plain DDP wrapper)."""
+    set-up than their finer overlap buys.  mode "rs_ag" (round 6): per_block's messages, each exchanged as reduce_scatter_tensor +
+    all_gather_into_tensor instead of one all_reduce -- SURVEY.md 8(e)'s all-peer pattern spelled out: every rank reduces 1/W of the message
+    from all W - 1 peers at once (over all seven xGMI links of the node) and then hands its shard to all of them, where a ring all-reduce
+    walks one link.  RCCL may pick the same schedule inside all_reduce by itself; bench.py --gpus N times all arrangements, so the first
+    8-GPU run says whether it does.  Messages whose length W does not divide fall back to all_reduce.  Same arithmetic up to fp32
+    summation order (a shard is summed on its owner instead of around a ring); replicas stay bit-identical, every rank receives the same
+    shards.  bench.py --gpus N times all three (and the plain DDP wrapper)."""
 
     def __init__(self, process_group=None, average=True, mode="per_block", bucket_bytes=400 << 20):
-        assert mode in ("per_block", "coarse"), mode
+        assert mode in ("per_block", "coarse", "rs_ag"), mode
         self.group = process_group
         self.average = average
         self.mode = mode
@@ -62,12 +68,36 @@ class GradSync:
             self._held.append(t)
             self._held_bytes += t.numel() * t.element_size()
             return None, None
-        self.launches += 1
         backend = dist.get_backend(self.group)
+        W = self.world_size
+        if self.mode == "rs_ag" and t.is_contiguous() and t.numel() % W == 0 and W > 1:
+            return self._reduce_scatter_gather(t, backend, W)
+        self.launches += 1
         if self.average and backend == "nccl":
             return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None
         work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         return work, ((1.0 / self.world_size) if self.average else None)    # gloo (CPU tests) has no AVG
+
+    def _reduce_scatter_gather(self, t, backend, W):
+        """In-place all-reduce of `t` as reduce-scatter + all-gather.  Both collectives are enqueued back to back on the group's own stream
+        (ProcessGroupNCCL orders a communicator's collectives), so the all-gather reads the shard the reduce-scatter wrote without a host
+        wait; the returned handle is the all-gather's.  gloo (the CPU / two-ranks-on-one-GPU tests) has no reduce-scatter: W reduce() calls,
+        shard r to rank r -- the same data movement, one message per shard."""
+        flat = t.view(-1)
+        n = flat.numel() // W
+        rank = dist.get_rank(self.group)
+        self.launches += 2
+        if backend == "nccl":
+            shard = torch.empty((n,), dtype=flat.dtype, device=flat.device)
+            op = dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM
+            dist.reduce_scatter_tensor(shard, flat, op=op, group=self.group, async_op=True)
+            return dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True), None
+        works = [dist.reduce(flat[r * n:(r + 1) * n], dst=dist.get_global_rank(self.group, r) if self.group is not None else r, op=dist.ReduceOp.SUM,
+                             group=self.group, async_op=True) for r in range(W)]
+        for w in works:
+            w.wait()
+        shard = flat[rank * n:(rank + 1) * n].clone()
+        return dist.all_gather_into_tensor(flat, shard, group=self.group, async_op=True), ((1.0 / W) if self.average else None)
 
     def _flush(self):
         """coarse mode: exchange everything collected so far as one coalesced collective."""

@@ -156,6 +156,45 @@ def test_gemm256_224_row_tile_bit_identical_to_256_row_tile(M, N, K):
     assert relerr(ref[1], x.float() @ w.float().t() + b) < 2e-5 * math.sqrt(K)
 
 
+@pytest.mark.parametrize("M,N,K", [(12544, 4096, 1024), (12544, 3072, 1024), (12500, 4096, 256), (12544, 16384, 256), (9000, 4096, 128)])
+def test_gemm256_mixed_full_and_half_tiles_bit_identical_to_uniform_tiles(M, N, K):
+    """Round 6: multi-round launches run whole rounds of 256-row tiles followed by HALF tiles of 128 rows for the remaining rows (gemm256.h,
+    MIXED: fc1 forward / fc2 data gradient 48 x 16 full + 2 x 16 half tiles, qkv forward 42 x 12 + 14 x 12, the decoder embedding 48 x 64 +
+    2 x 64; a ragged M whose last half tile is mostly padding; a shape whose rule picks a mixed plan with many half tiles).  In a half tile
+    both wave rows work on the 128 rows of wave row 0 (row 0: phases 0 / 1, row 1: phases 2 / 3) -- same ascending K order per output element,
+    so every epilogue must return the bits of the uniform tiling (pa_debug_set(12, 1) = the round-5 plans), including the column sums the
+    fc2 data-gradient epilogue emits (one partial row per (row tile, wave row): another row count, same sums up to fp32 summation order)."""
+    from painter_amd._lib import lib
+    T = torch.bfloat16
+    x, w, b = gen((M, K), 1, 1.0, T), gen((N, K), 2, 0.05, T), gen((N,), 3)
+    resid = gen((M, N), 4) if N <= 4096 else None
+    rowscale = gen(((M + 7) // 8,), 5).abs() + 0.5
+    # data gradient of a Linear(N -> K): dX [M, N] = dY [M, K] . W [K, N] -- the OUTPUT is the wide side, as in fc2's backward
+    dy, w2, aux2 = gen((M, K), 6, 1.0, T), gen((K, N), 7, 0.05, T), gelu_aux_of(gen((M, N), 9, 1.0, T))
+    pix = N == 16384
+
+    def run():
+        act, aux = ops.linear_gelu(x, w, b)
+        cs = torch.full((N,), float("nan"), device=DEV)
+        res = [ops.linear_fwd(x, w, b, EPI_BIAS), act, aux, ops.linear_dgrad(dy, w2), ops.linear_dgrad(dy, w2, gelu_aux=aux2, colsum_out=cs)]
+        if resid is not None:
+            res += [ops.linear_fwd(x, w, b, EPI_BIAS_F32), ops.linear_fwd(x, w, b, EPI_BIAS_RESID, resid=resid, rowscale=rowscale, rows_per_sample=8)]
+        if pix and M == 12544:
+            res.append(ops.linear_pixshuf(x, w, b, 8, 56, 28, 16, 64))
+        return res, cs
+    try:
+        assert lib.pa_debug_set(12, 1) == 0
+        ref, cs_ref = run()
+        assert lib.pa_debug_set(12, 0) == 0
+        got, cs_got = run()
+    finally:
+        lib.pa_debug_set(12, 0)
+    for a, r in zip(got, ref):
+        assert torch.equal(a, r)
+    assert relerr(cs_got, cs_ref) < 1e-5 and relerr(cs_got, got[4].double().sum(0)) < 4e-3
+    assert relerr(ref[0].float(), x.float() @ w.float().t() + b) < 1e-2
+
+
 @pytest.mark.parametrize("M,N,K", [(12544, 1024, 4096), (1568, 1024, 1024), (500, 256, 264), (96, 128, 136)])
 @pytest.mark.parametrize("T", [torch.bfloat16, torch.float32])
 def test_linear_dgrad_column_sums_from_the_epilogue(T, M, N, K):
@@ -254,15 +293,15 @@ def test_linear_strided_views_and_pixshuf(T):
 @pytest.mark.parametrize("R,D,variant", [(64, 128, 0), (1000, 1024, 0), (1003, 1024, 0), (25088, 1024, 0), (33, 1280, 0), (4099, 1280, 0),
                                          (1000, 1024, 1), (1003, 1024, 1), (25088, 1024, 1), (33, 1280, 1), (4099, 1280, 1)])
 def test_layernorm_fwd_bwd(T, R, D, variant):
-    """variant (pa_debug_set(5, .)): 0 = the default backward (rows split over the workgroup's waves wherever D >= 1024, batches of 2 rows;
+    """variant (pa_debug_set(10, .)): 0 = the default backward (rows split over the workgroup's waves wherever D >= 1024, batches of 2 rows;
     R = 1003 / 33 / 4099 end in a half-filled batch), 1 = one wave per row everywhere (what D = 128 always runs)."""
     from painter_amd._lib import lib
-    saved = lib.pa_debug_get(5)
-    lib.pa_debug_set(5, variant)
+    saved = lib.pa_debug_get(10)
+    lib.pa_debug_set(10, variant)
     try:
         _layernorm_fwd_bwd(T, R, D)
     finally:
-        lib.pa_debug_set(5, saved)
+        lib.pa_debug_set(10, saved)
 
 
 def _layernorm_fwd_bwd(T, R, D):

@@ -48,13 +48,21 @@ def build(cfg, seed, dtype, train=False):
 # sum to zero, under a 2^-9 rounding of every P, dS and bias-table entry -- is a property of bf16 arithmetic on this model that the
 # reference shows to the same degree, not a loose kernel.  The head_dim-80 small model has short tensors (few samples per tensor, larger
 # spread: 4.0e-2 .. 6.3e-2 measured) and no yardstick of its own: 1e-1 there.
-BF16_SAMPLE_GATE = 3.0e-2          # every tensor except the rel-pos tables, ViT-L fixtures: 1.5 x the reference's own 1.95e-2
+BF16_SAMPLE_GATE = 2.45e-2         # every tensor except the rel-pos tables, ViT-L fixtures: 1.25 x the reference's own 1.95e-2 (round 6; 1.5 x before)
+# Round 6 ("find what blocks.0.attn.qkv.weight loses").  Nothing: the sampled rel-max is the MAXIMUM over ~3000 samples
+# of one tensor, a heavy-tailed estimator -- per block and weight family (tools/grad_yardstick.py, profiles/r06_grad_yardstick_per_block.log) the HIP
+# bf16 build sits BELOW the reference's own bf16-autocast deviation on every one of the 96 big matrices by whole-tensor relative Frobenius error
+# (qkv.weight of block 0: 9.9e-3 against the reference's 1.07e-2; worst matrix 1.12e-2 against 1.28e-2; both grow by ~10 % from block 23 to
+# block 0: rounding accumulated along the residual chain, the same in both), and its rel-max exceeds the reference's on one tensor of 101 by
+# chance.  So the gate that can see a systematic loss is a Frobenius one: over the stored samples of each of the blocks' 96 weight matrices,
+# at 1.0 x the reference's own worst matrix.
+BF16_SAMPLE_FRO_GATE = 1.3e-2      # ViT-L fixtures: relative Frobenius error over the samples of a tensor (reference's own worst matrix: 1.28e-2; HIP: 1.12e-2)
 BF16_SAMPLE_GATE_SHORT = 1.0e-1    # the head_dim-80 small models
 BF16_RELPOS_FRO_GATE = 5.0e-2      # rel-pos tables: relative Frobenius error over the full tensor (reference's own: 4.17e-2)
 BF16_RELPOS_GATE = 1.9e-1          # rel-pos tables: sampled rel-max, 1.5 x the reference's own 1.28e-1
 
 
-def _check_bf16_samples(fx, case, m, tag, rtol_norm=1e-1, atol_dot=5e-2, small_rtol=1e-1, sample_gate=BF16_SAMPLE_GATE):
+def _check_bf16_samples(fx, case, m, tag, rtol_norm=1e-1, atol_dot=5e-2, small_rtol=1e-1, sample_gate=BF16_SAMPLE_GATE, sample_fro_gate=None):
     """bf16 build against a reference fixture: digests at the model-level bf16 bounds, the sampled gradients at the gates above."""
     rep = []
     G.check_grad_digests(fx, case, [(n, p.grad) for n, p in m.named_parameters()], rtol_norm, atol_dot, small_rtol, sample_rtol=1e9, report=rep)
@@ -71,6 +79,16 @@ def _check_bf16_samples(fx, case, m, tag, rtol_norm=1e-1, atol_dot=5e-2, small_r
     assert not rel or max(rel)[0] < BF16_RELPOS_GATE, max(rel)
     assert not oth or max(oth)[0] < sample_gate, max(oth)
     assert not fro or max(fro)[0] < BF16_RELPOS_FRO_GATE, max(fro)
+    if sample_fro_gate is not None:
+        sfro = []
+        for n, p in m.named_parameters():
+            key = "%sgrad_sample/%s" % (case, n)
+            if key in fx.files and n.startswith("blocks.") and n.endswith(".weight") and p.dim() == 2:      # the 96 matrices the yardstick lists per block
+                b = torch.as_tensor(fx[key]).reshape(-1)
+                a = p.grad.detach().float().cpu().reshape(-1)
+                sfro.append((G.rel_fro(a[::int(fx[case + "grad_sample_stride"])], b), n))
+        print("%s: worst relative Frobenius error over the samples of a block's weight matrix: %.3e (%s), %d tensors" % ((tag,) + max(sfro) + (len(sfro),)))
+        assert max(sfro)[0] < sample_fro_gate, max(sfro)
 
 
 def run_painter(m, cfg, batch, seed_x, mask_kind, backward=True):
@@ -289,7 +307,7 @@ def test_vit_large_bf16_loss_and_pred_yardstick():
     flat = pred.reshape(-1).cpu()
     stride = int(fx[case + "pred_stride"])
     assert G.rel_fro(flat[::stride], fx[case + "pred_sample"]) < 3e-2      # reference's own bf16 deviation: 1e-2
-    _check_bf16_samples(fx, case, m, "ViT-L B=1 bf16")
+    _check_bf16_samples(fx, case, m, "ViT-L B=1 bf16", sample_fro_gate=BF16_SAMPLE_FRO_GATE)
 
 
 def _vitl_b8_case(dtype):
@@ -329,7 +347,7 @@ def test_vit_large_b8_train_bf16_vs_reference_golden():
     assert abs(loss.item() - ref_loss) < 2e-3 * abs(ref_loss), (loss.item(), ref_loss)
     worst = max(G.rel_fro(ps[b_], fx[case + "pred_sample"][b_]) for b_ in range(8))
     assert worst < 3e-2, worst
-    _check_bf16_samples(fx, case, m, "ViT-L B=8 train bf16 (the timed configuration)")
+    _check_bf16_samples(fx, case, m, "ViT-L B=8 train bf16 (the timed configuration)", sample_fro_gate=BF16_SAMPLE_FRO_GATE)
 
 
 def test_seggpt_vit_large_n32_ensemble_and_hipgraph_vs_reference_golden():

@@ -56,7 +56,9 @@ def _worker(rank, world, port, q, mode="per_block"):
         ref /= world
         ok &= bool(torch.allclose(G[n], ref, atol=1e-6)) and G[n].shape == torch.Size(s)
     ok &= not hasattr(sync, "set_sync")          # there is no way to skip a micro-step's exchange (replicas would diverge)
-    ok &= sync.launches == (2 if mode == "coarse" else 4)      # per_block: 2 matrices in place + 2 flattened messages; coarse: 2 coalesced launches
+    # per_block: 2 matrices in place + 2 flattened messages; coarse: 2 coalesced launches; rs_ag: the two matrices and the 20-element message
+    # as reduce-scatter + all-gather pairs, the 19-element message (2 does not divide it) as one all-reduce
+    ok &= sync.launches == {"coarse": 2, "per_block": 4, "rs_ag": 7}[mode]
     # the engine's per-block arrangement: the small gradients are views of ONE pre-allocated flat buffer, exchanged in place as one
     # message (no flattening copy); the big matrix goes in place as before
     g2 = torch.Generator().manual_seed(500 + rank)
@@ -158,15 +160,16 @@ def _run(target, world=2, mode="per_block"):
 import pytest  # noqa: E402
 
 
-@pytest.mark.parametrize("mode", ["per_block", "coarse"])
+@pytest.mark.parametrize("mode", ["per_block", "coarse", "rs_ag"])
 def test_gradsync_world2_gloo(mode):
-    """mode "coarse" (round 5): the same gradients, collected and exchanged as a few coalesced launches -- the same averages."""
+    """mode "coarse" (round 5): the same gradients, collected and exchanged as a few coalesced launches -- the same averages.
+    mode "rs_ag" (round 6): every message as reduce-scatter + all-gather (gloo: W reduce() calls stand in for the reduce-scatter)."""
     res = _run(_worker, mode=mode)
     assert [r for r, _ in res] == [0, 1]
     assert all(ok for _, ok in res), res
 
 
-@pytest.mark.parametrize("mode", ["per_block", "coarse"])
+@pytest.mark.parametrize("mode", ["per_block", "coarse", "rs_ag"])
 def test_gradsync_world2_model_gradients_with_accumulation(mode):
     from oracle import painter_oracle as O
     res = _run(_worker_model, mode=mode)

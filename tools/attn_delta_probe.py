@@ -19,7 +19,8 @@ sys.path.insert(0, ".")
 sys.path.insert(0, "tools")
 from attn3_diag import attn_reference, fro, rel      # noqa: E402
 from painter_amd import ops                          # noqa: E402
-from painter_amd._lib import check, code, lib, p     # noqa: E402
+from painter_amd._lib import check, lib              # noqa: E402
+from painter_amd.ops import code, p                  # noqa: E402
 
 DEV = "cuda"
 

@@ -59,8 +59,8 @@ for s in "$@"; do
     hostq)     timeout 300 python tools/host_enqueue.py > gpurun_out/hostq.log 2>&1; echo "hostq rc=$?"; tail -6 gpurun_out/hostq.log ;;
     lnrows)    timeout 400 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "layernorm" > gpurun_out/lnrows_tests.log 2>&1; echo "tests rc=$?"; tail -2 gpurun_out/lnrows_tests.log
                timeout 300 python tools/ln_bwd_bench.py > gpurun_out/lnrows_bench.log 2>&1; echo "bench rc=$?"; cat gpurun_out/lnrows_bench.log
-               timeout 500 python tools/step_knob_ab.py 5 6 "LN backward rows split over waves (round 5):5=0" "one wave per row (before):5=1" > gpurun_out/lnrows_ab.log 2>&1; echo "ab rc=$?"; tail -3 gpurun_out/lnrows_ab.log ;;
-    lnvar)     timeout 600 python tools/step_knob_ab.py 5 6 "LN bwd 4-row batches, 3 per CU:5=0" "one wave per row:5=1" "2-row batches, 4 per CU:5=2" "2-row batches, 5 per CU:5=3" > gpurun_out/lnvar_ab.log 2>&1; echo "ab rc=$?"; tail -5 gpurun_out/lnvar_ab.log ;;
+               timeout 500 python tools/step_knob_ab.py 5 6 "LN backward rows split over waves (round 5):10=0" "one wave per row (before):10=1" > gpurun_out/lnrows_ab.log 2>&1; echo "ab rc=$?"; tail -3 gpurun_out/lnrows_ab.log ;;
+    lnvar)     timeout 600 python tools/step_knob_ab.py 5 6 "LN bwd 4-row batches, 3 per CU:10=0" "one wave per row:10=1" "2-row batches, 4 per CU:10=2" "2-row batches, 5 per CU:10=3" > gpurun_out/lnvar_ab.log 2>&1; echo "ab rc=$?"; tail -5 gpurun_out/lnvar_ab.log ;;
     lastcheck) timeout 500 python -m pytest tests/test_kernels_gpu.py tests/test_parallel_gpu.py -m gpu -q -k "layernorm or bench or GradSync" > gpurun_out/lastcheck.log 2>&1; echo "lastcheck rc=$?"; tail -3 gpurun_out/lastcheck.log ;;
     selftest)  PAINTER_AMD_DDP_SELFTEST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29547 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 300 python tools/ddp_selftest.py > gpurun_out/selftest.log 2>&1; echo "selftest rc=$?"; tail -4 gpurun_out/selftest.log ;;
     profhuge)  (cd /tmp && PAINTER_AMD_SIDE_STREAM=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OLDPWD/gpurun_out/prof_huge -o huge -- python $OLDPWD/bench.py --model vit_huge --steps 3 --warmup 1 --no-cpu-baseline --no-optimizer --no-reference-gpu --no-secondary --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/prof_huge.log 2>&1); echo "profhuge done"; ls gpurun_out/prof_huge | head -3 ;;
@@ -73,6 +73,14 @@ for s in "$@"; do
     engab)     timeout 600 python tools/step_engine_ab.py 5 6 "delta in dQ + colsum in epilogue (default):_ATTN_PREP=fused,_FC1_COLSUM=epilogue" "prep launch:_ATTN_PREP=launch,_FC1_COLSUM=epilogue" "separate fc1 column sums:_ATTN_PREP=fused,_FC1_COLSUM=separate" > gpurun_out/engab.log 2>&1; echo "engab rc=$?"; tail -4 gpurun_out/engab.log ;;
     libab)     timeout 900 python tools/step_lib_ab.py 3 6 "round-5 build=painter_amd/lib/libpainter_hip.so" "baseline build=painter_amd/lib/libpainter_hip_base.so" > gpurun_out/libab.log 2>&1; echo "libab rc=$?"; tail -4 gpurun_out/libab.log ;;
     r5quick)   timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -s -x -k "conv64 or decoder_tail or small or vitl_b8 or vit_large_b8 or gemm256" > gpurun_out/r5quick.log 2>&1; echo "r5quick rc=$?"; grep -a "passed\|failed\|rror" gpurun_out/r5quick.log | tail -5 ;;
+    r6attn)    timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -s -x -k "attn or vit_large or small_painter or small_seggpt" > gpurun_out/r6attn.log 2>&1; echo "r6attn rc=$?"; grep -a "passed\|failed\|rror\|worst" gpurun_out/r6attn.log | tail -12 ;;
+    libab6)    timeout 900 python tools/step_lib_ab.py 3 6 "round-6 build=painter_amd/lib/libpainter_hip.so" "round-5 library=painter_amd/lib/libpainter_hip_base.so" > gpurun_out/libab6.log 2>&1; echo "libab6 rc=$?"; tail -4 gpurun_out/libab6.log ;;
+    r6gemm)    timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -s -x -k "gemm256 or linear or vit_large or small_painter" > gpurun_out/r6gemm.log 2>&1; echo "r6gemm rc=$?"; grep -a "passed\|failed\|rror\|worst" gpurun_out/r6gemm.log | tail -12 ;;
+    mixedab)   timeout 600 python tools/step_knob_ab.py 4 6 "full rounds + half tiles (round 6):12=0" "uniform tiles (round 5):12=1" > gpurun_out/mixedab.log 2>&1; echo "mixedab rc=$?"; tail -3 gpurun_out/mixedab.log ;;
+    lntests)   timeout 300 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "layernorm" > gpurun_out/lntests.log 2>&1; echo "lntests rc=$?"; tail -2 gpurun_out/lntests.log ;;
+    mixedprobe) timeout 300 python tools/gemm_mixed_probe.py > gpurun_out/mixedprobe.log 2>&1; echo "mixedprobe rc=$?"; cat gpurun_out/mixedprobe.log ;;
+    lnfwdab)   timeout 600 python tools/step_knob_ab.py 4 6 "LN forward, persistent waves (round 6):13=1" "one row per wave (round 5):13=0" > gpurun_out/lnfwdab.log 2>&1; echo "lnfwdab rc=$?"; tail -3 gpurun_out/lnfwdab.log ;;
+    deltaprobe) timeout 300 python tools/attn_delta_probe.py > gpurun_out/deltaprobe.log 2>&1; echo "deltaprobe rc=$?"; cat gpurun_out/deltaprobe.log ;;
     *)         echo "unknown section $s" ;;
   esac
 done

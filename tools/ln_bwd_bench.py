@@ -1,4 +1,4 @@
-"""LayerNorm backward, the two variants of pa_debug_set(5, .) interleaved in one process: 0 = rows split over the workgroup's waves (round 5,
+"""LayerNorm backward, the two variants of pa_debug_set(10, .) interleaved in one process: 0 = rows split over the workgroup's waves (round 5,
 D >= 1024), 1 = one wave per row (rounds 1 - 4).  Times the launch with its partial-row reduction (as the engine's non-deferred calls run
 it) at the ViT-L (R = 12544 and 25088, D = 1024) and ViT-H/14 (R = 8192, D = 1280) shapes, with the bf16 copy and the column sums the
 engine asks for, and prints the rate over the algorithmic bytes (dy 2 + x 4 + dres 4 + dx 4 + dxT 2 bytes per element)."""
@@ -30,7 +30,7 @@ def timeit(f, n=40):
 
 def main():
     g = torch.Generator().manual_seed(0)
-    saved = lib.pa_debug_get(5)
+    saved = lib.pa_debug_get(10)
     try:
         for R, D in ((12544, 1024), (25088, 1024), (8192, 1280)):
             x = torch.randn(R, D, generator=g).to(DEV)
@@ -43,14 +43,14 @@ def main():
             res = {0: [], 1: []}
             for _ in range(4):
                 for v in (0, 1):
-                    lib.pa_debug_set(5, v)
+                    lib.pa_debug_set(10, v)
                     res[v].append(timeit(lambda: ops.layernorm_bwd(dy, x, mean, rstd, gam, dres=dres, dx=dres, dxT=dxT, dxT_colsum=cs)))
             for v in (0, 1):
                 us = statistics.median(res[v])
                 print("R %5d D %4d variant %d: %6.1f us (kernel + partial-row reduction)  %.2f TB/s algorithmic  (%s)"
                       % (R, D, v, us, R * D * 16 / us / 1e6, " ".join("%.1f" % t for t in res[v])), flush=True)
     finally:
-        lib.pa_debug_set(5, saved)
+        lib.pa_debug_set(10, saved)
 
 
 if __name__ == "__main__":
