@@ -83,3 +83,39 @@ def test_committed_pmc_traffic_is_stamped_with_the_built_library():
     assert set(alg) == {k for k in tj if not k.startswith("_")}
     for k, v in alg.items():
         assert 0.9 <= tj[k]["hbm_bytes_per_launch"] / v["bytes"] < 4.0, (k, tj[k]["hbm_bytes_per_launch"], v["bytes"])
+
+
+def test_closing_profiles_of_the_round_carry_one_library_stamp():
+    """Round 6: the closing artefacts of rounds 4 and 5 were taken one commit before the shipped library.  Every
+    profiles/r06_* file that tools/adopt_profiles.py filed starts with `# library <sha16> git <head> | <command>`; the CLOSING set (the
+    kernel statistics of the one- and two-stream step, the matrix-pipe counters, the PMC traffic file, the bench line) must all name the
+    SAME library, and where this tree's build reproduces the measured binary that hash must be the built library's."""
+    import glob
+    import json
+    import os
+    import re
+    prof = os.path.join(bench.ROOT, "profiles")
+    stamps = {}
+    for f in sorted(glob.glob(os.path.join(prof, "r06_*.csv")) + glob.glob(os.path.join(prof, "r06_*.log"))):
+        first = open(f).readline()
+        if os.path.basename(f).startswith("r06_ab_"):
+            continue                                     # A/B logs describe experiments (often reverted): free-form headers
+        m = re.match(r"# library ([0-9a-f]{16}) git (\S+) \| ", first)
+        assert m, "%s lacks the `# library <sha16> git <head> | <command>` header of tools/adopt_profiles.py" % os.path.basename(f)
+        stamps[os.path.basename(f)] = m.group(1)
+    closing = ["r06_bench_one_stream_kernel_stats.csv", "r06_bench_two_stream_kernel_stats.csv", "r06_pmc_mfma_busy_per_kernel.csv"]
+    have = [c for c in closing if c in stamps]
+    if not have:
+        import pytest
+        pytest.skip("the closing profiles of round 6 are not filed yet")
+    shas = {stamps[c] for c in have}
+    tj = json.load(open(os.path.join(prof, "roofline_traffic.json")))
+    shas.add(tj["_meta"]["lib_sha16"])
+    line = os.path.join(prof, "r06_bench_line.json")
+    if os.path.exists(line):
+        shas.add(json.loads(open(line).read().strip().splitlines()[-1])["build"]["lib_sha16"])
+    assert len(shas) == 1, "closing artefacts were taken on different libraries: %s" % {c: stamps[c] for c in have}
+    built = bench._lib_sha16()
+    if built is not None and built not in shas:
+        import pytest
+        pytest.skip("closing artefacts are stamped %s, the library built here is %s (another path / toolchain, or kernels changed after the closing visit)" % (shas, built))

@@ -144,9 +144,13 @@ def test_bench_multi_rank_branch_runs_with_two_gloo_ranks_on_one_gpu():
     # round 5: the N > 1 branch times three gradient-exchange arrangements back to back (per-block GradSync, four coarse coalesced
     # launches, the plain DDP wrapper); all three must have run, agree on the loss of their last step (same parameters, same batch, no
     # optimizer, eval mode so that DropPath draws nothing: 1e-5 -- the arrangements only differ in HOW the same averaged gradients travel) and `value` must be the best of them
+    # round 6: a fourth arrangement (rs_ag: every per-block message as reduce-scatter + all-gather), and every arrangement carries its
+    # exposed communication = its step time minus the step time of the same process with no exchange at all
     gv = out["extra"]["gradsync_variants"]
-    assert set(gv) == {"per_block", "coarse", "ddp"} and out["extra"]["gradsync_chosen"] in gv
-    assert gv["per_block"]["collective_launches_per_step"] > gv["coarse"]["collective_launches_per_step"] >= 1
+    assert set(gv) == {"per_block", "coarse", "rs_ag", "ddp"} and out["extra"]["gradsync_chosen"] in gv, (sorted(gv), out["extra"].get("gradsync_errors"))
+    assert gv["rs_ag"]["collective_launches_per_step"] > gv["per_block"]["collective_launches_per_step"] > gv["coarse"]["collective_launches_per_step"] >= 1
+    assert out["extra"]["no_exchange_ms_per_step"] > 0 and all("exposed_comm_ms" in v for v in gv.values())
+    assert abs(out["extra"]["exposed_comm_ms"] - gv[out["extra"]["gradsync_chosen"]]["exposed_comm_ms"]) < 1e-9
     assert abs(out["value"] - max(v["value"] for v in gv.values())) < 1e-6 * out["value"]
     ls = [v["loss"] for v in gv.values()]
     assert max(ls) - min(ls) <= 1e-5 * abs(ls[0]), ls
