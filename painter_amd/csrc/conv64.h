@@ -45,6 +45,24 @@ DEVI bf16x8 tr_frag(const unsigned char* lo, const unsigned char* hi) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(l, h, 0, 1, 2, 3));
 }
 
+// Epilogue stores of the tile kernel (round 6).  A lane owns one pixel and 4-channel runs of it (MFMA D layout), so storing from registers is
+// 16 eight-byte stores per 32-pixel block, each touching 32 different 128-byte pixel rows -- store-issue-bound (the same finding as the GEMM
+// and attention epilogues).  Instead the wave passes a [32 px][64 ch] bf16 block through 4 KB of LDS (16-byte chunk index XOR (px & 7): the
+// 8-byte writes of a half-wave spread over all banks, the 16-byte reads of 8 lanes cover one row conflict-free) and stores whole pixel rows:
+// 4 sixteen-byte stores per block, 8 lanes per 128-byte row.
+DEVI void px_stage4(unsigned char* stg, int px, int c, uint2 v) {          // channels c .. c + 3 (c % 4 == 0) of pixel px (0..31)
+    *reinterpret_cast<uint2*>(stg + px * 128 + (((c >> 3) ^ (px & 7)) << 4) + (c & 7) * 2) = v;
+}
+// row(px) -> destination of that pixel's 64 channels; valid(px) -> store it?
+template <class RowFn> DEVI void px_write_rows(const unsigned char* stg, int lane, RowFn&& row) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int px = (lane >> 3) + 8 * i, ch = lane & 7;
+        bf16* dst = row(px);
+        if (dst != nullptr) *reinterpret_cast<uint4*>(dst + ch * 8) = *reinterpret_cast<const uint4*>(stg + px * 128 + ((ch ^ (px & 7)) << 4));
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ forward / dgrad
 // x: NHWC [B, Hi, Wi, 64] bf16; w: [64 out][9 taps][64 in] bf16; Hi % 4 == 0, Wi % 64 == 0.
 // Epi(acc[2][2], 0, first pixel (linear index) of the wave's 64-pixel run, lane, 0): acc[bi][bj][r] = out channel bi*32 + acc_row(r),
@@ -73,18 +91,25 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const bf16* __rest
             if (gy >= 0 && gy < Hi && gx >= 0 && gx < Wi) xr[i] = *reinterpret_cast<const uint4*>(img + ((size_t)gy * Wi + gx) * 64 + ch * 8);
         }
     }
-    uint4 wr0, wr1;
+    // The taps' weights go global -> registers -> LDS double buffer.  Round 6: the registers are loaded TWO taps ahead (two register pairs,
+    // alternating): with one tap of cover (16 MFMAs = 512 cycles) every tap's LDS store sat waiting for an L2 round trip in front of the
+    // tap's barrier -- nine exposed round trips per tile, matrix pipe busy 0.20.
+    uint4 wa0, wa1, wb0, wb1;                        // (named registers: an indexed pair went to scratch)
     const int wco0 = tid >> 3, wch = tid & 7;       // weight chunk of this thread: rows wco0 and wco0 + 32
-    auto load_w = [&](int tap) {
-        wr0 = *reinterpret_cast<const uint4*>(w + ((size_t)wco0 * 9 + tap) * 64 + wch * 8);
-        wr1 = *reinterpret_cast<const uint4*>(w + ((size_t)(wco0 + 32) * 9 + tap) * 64 + wch * 8);
+    auto load_w = [&](auto tap_c) {
+        constexpr int tap = decltype(tap_c)::value;
+        const uint4 v0 = *reinterpret_cast<const uint4*>(w + ((size_t)wco0 * 9 + tap) * 64 + wch * 8);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(w + ((size_t)(wco0 + 32) * 9 + tap) * 64 + wch * 8);
+        if constexpr (tap & 1) { wb0 = v0; wb1 = v1; } else { wa0 = v0; wa1 = v1; }
     };
-    auto store_w = [&](int buf) {
-        unsigned char* d = smem + F_XB + buf * F_WB + wco0 * 128 + ((wch ^ vsw(wco0)) << 4);
-        *reinterpret_cast<uint4*>(d) = wr0;
-        *reinterpret_cast<uint4*>(d + 4096) = wr1;
+    auto store_w = [&](auto tap_c) {
+        constexpr int tap = decltype(tap_c)::value;
+        unsigned char* d = smem + F_XB + (tap & 1) * F_WB + wco0 * 128 + ((wch ^ vsw(wco0)) << 4);
+        *reinterpret_cast<uint4*>(d) = (tap & 1) ? wb0 : wa0;
+        *reinterpret_cast<uint4*>(d + 4096) = (tap & 1) ? wb1 : wa1;
     };
-    load_w(0);
+    load_w(IC<0>{});
+    load_w(IC<1>{});
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int idx = tid + 256 * i;
@@ -93,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const bf16* __rest
             *reinterpret_cast<uint4*>(smem + xbyte(r * HS + c, ch)) = xr[i];
         }
     }
-    store_w(0);
+    store_w(IC<0>{});
     __syncthreads();
 
     // fragment addresses: weights row (lane & 31) [+32 rows = +4096]; pixels: halo row `wave` (+ (dy+1) rows by immediate),
@@ -116,7 +141,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const bf16* __rest
 
     auto do_tap = [&](auto tap_c) {
         constexpr int tap = decltype(tap_c)::value, dyi = tap / 3, dxi = tap % 3;
-        if constexpr (tap + 1 < 9) load_w(tap + 1);
         const unsigned char* wimg = smem + (tap & 1) * F_WB;
         const unsigned char* ximg = smem + dyi * HS * 128;
 #pragma unroll
@@ -128,12 +152,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tile_kernel(const bf16* __rest
             acc[1][0] = mfma(a1, b0, acc[1][0]);
             acc[1][1] = mfma(a1, b1, acc[1][1]);
         }
-        if constexpr (tap + 1 < 9) store_w((tap + 1) & 1);
+        if constexpr (tap + 1 < 9) store_w(IC<tap + 1>{});    // (loaded during tap - 1; its register pair is free again behind this store)
+        if constexpr (tap + 2 < 9) load_w(IC<tap + 2>{});
         __syncthreads();
     };
     do_tap(IC<0>{}); do_tap(IC<1>{}); do_tap(IC<2>{}); do_tap(IC<3>{}); do_tap(IC<4>{});
     do_tap(IC<5>{}); do_tap(IC<6>{}); do_tap(IC<7>{}); do_tap(IC<8>{});
-    epi(acc, 0, (int)(((size_t)b * Hi + y0 + wave) * Wi + x0), lane, 0);
+    // (every tap ends with a barrier: the halo image and the weight buffers are dead -- 8 KB of staging per wave for the epilogue's stores)
+    epi(acc, 0, (int)(((size_t)b * Hi + y0 + wave) * Wi + x0), lane, 0, smem + wave * 8192);
 }
 
 template <class Epi> static int launch_tile(const bf16* x, const bf16* w, Epi epi, int Bn, int Hi, int Wi, hipStream_t st) {

@@ -315,7 +315,9 @@ template <typename T, bool FAST = false> struct EpiTail {
     float* pred;     // NCHW [B, 3, Hi, Wi]
     int HW, N;       // pixels per image, total pixels
     float eps;
-    DEVI void operator()(const f32x16 (&acc)[2][2], int ib, int jb, int lane, int) const {
+    DEVI void operator()(const f32x16 (&acc)[2][2], int ib, int jb, int lane, int z) const { (*this)(acc, ib, jb, lane, z, nullptr); }
+    // stg (tile kernel, bf16): 8 KB of wave-private LDS -- y3 leaves as whole 128-byte pixel rows (c64::px_stage4 / px_write_rows)
+    DEVI void operator()(const f32x16 (&acc)[2][2], int ib, int jb, int lane, int, unsigned char* stg) const {
         // ib == 0 (WM == 1): acc[bi][bj][r] -> cout = bi*32 + acc_row(r), pixel = jb + bj*32 + (lane & 31)
         const int g = lane >> 5;
 #pragma unroll
@@ -338,10 +340,21 @@ template <typename T, bool FAST = false> struct EpiTail {
                     for (int e = 0; e < 4; ++e) y[o + e] = to_f(from_f<T>(y[o + e]));
                     if (y3 && pix < N) {
                         typename TT<T>::Vec4 pk = cvt4(y[o], y[o + 1], y[o + 2], y[o + 3], (T*)nullptr);
-                        *reinterpret_cast<typename TT<T>::Vec4*>(y3 + (size_t)pix * CV_C + bi * 32 + 8 * rg + 4 * g) = pk;
+                        if constexpr (std::is_same<T, bf16>::value) {
+                            if (stg != nullptr) c64::px_stage4(stg + bj * 4096, lane & 31, bi * 32 + 8 * rg + 4 * g, pk);
+                            else *reinterpret_cast<typename TT<T>::Vec4*>(y3 + (size_t)pix * CV_C + bi * 32 + 8 * rg + 4 * g) = pk;
+                        } else {
+                            *reinterpret_cast<typename TT<T>::Vec4*>(y3 + (size_t)pix * CV_C + bi * 32 + 8 * rg + 4 * g) = pk;
+                        }
                     }
                     s += (y[o] + y[o + 1]) + (y[o + 2] + y[o + 3]);
                 }
+            if constexpr (std::is_same<T, bf16>::value) {
+                if (y3 && stg != nullptr) {          // (same-wave LDS operations are ordered: no barrier)
+                    const int p0 = jb + bj * 32;
+                    c64::px_write_rows(stg + bj * 4096, lane, [&](int px) { return p0 + px < N ? y3 + (size_t)(p0 + px) * CV_C : (T*)nullptr; });
+                }
+            }
             s += lane_xor32(s);
             const float mu = s * (1.f / CV_C);
             float q = 0.f;
@@ -360,8 +373,13 @@ template <typename T, bool FAST = false> struct EpiTail {
                                  wc = *reinterpret_cast<const float4*>(w1 + 2 * CV_C + c0);
                     const float z0 = (y[o + 0] - mu) * rs * ga.x + be.x, z1 = (y[o + 1] - mu) * rs * ga.y + be.y,
                                 z2 = (y[o + 2] - mu) * rs * ga.z + be.z, z3 = (y[o + 3] - mu) * rs * ga.w + be.w;
-                    const float a0 = FAST ? gelu_fast(z0) : gelu_f(z0), a1 = FAST ? gelu_fast(z1) : gelu_f(z1),
-                                a2 = FAST ? gelu_fast(z2) : gelu_f(z2), a3 = FAST ? gelu_fast(z3) : gelu_f(z3);
+                    float a0, a1, a2, a3;
+                    if constexpr (FAST) {       // packed pairs (round 6): the epilogue is VALU-bound (busy 0.55), half of it this GELU
+                        const f32x2_t p01 = gelu_fast2(z0, z1), p23 = gelu_fast2(z2, z3);
+                        a0 = p01[0]; a1 = p01[1]; a2 = p23[0]; a3 = p23[1];
+                    } else {
+                        a0 = gelu_f(z0); a1 = gelu_f(z1); a2 = gelu_f(z2); a3 = gelu_f(z3);
+                    }
                     o0 += (a0 * wa.x + a1 * wa.y) + (a2 * wa.z + a3 * wa.w);
                     o1 += (a0 * wb.x + a1 * wb.y) + (a2 * wb.z + a3 * wb.w);
                     o2 += (a0 * wc.x + a1 * wc.y) + (a2 * wc.z + a3 * wc.w);
@@ -437,20 +455,24 @@ template <typename T> struct EpiUnshuf {
 // the same for the tile kernel's orientation (lane = pixel, registers = channels): 8-byte runs of 4 channels
 struct EpiUnshufPx {
     bf16* out; int Hp, Wp, P;
-    DEVI void operator()(const f32x16 (&acc)[2][2], int, int jb, int lane, int) const {
+    // stg: 8 KB of wave-private LDS (round 6): a pixel's 64 channels leave as one 128-byte row, 8 lanes x 16 bytes (c64::px_write_rows)
+    DEVI void operator()(const f32x16 (&acc)[2][2], int, int jb, int lane, int, unsigned char* stg) const {
         const int Wi = Wp * P, HW = Hp * P * Wi, g = lane >> 5;
 #pragma unroll
         for (int bj = 0; bj < 2; ++bj) {
-            const int pix = jb + bj * 32 + (lane & 31);
-            const int b = pix / HW, rem = pix % HW, y = rem / Wi, x = rem % Wi;
-            const int h = y / P, p = y % P, w = x / P, q = x % P;
-            bf16* dst = out + (((size_t)b * Hp + h) * Wp + w) * (size_t)(P * P * CV_C) + (size_t)(p * P + q) * CV_C;
 #pragma unroll
             for (int bi = 0; bi < 2; ++bi)
 #pragma unroll
                 for (int rg = 0; rg < 4; ++rg)
-                    *reinterpret_cast<uint2*>(dst + bi * 32 + 8 * rg + 4 * g) =
-                        make_uint2(pack_bf16x2(acc[bi][bj][rg * 4], acc[bi][bj][rg * 4 + 1]), pack_bf16x2(acc[bi][bj][rg * 4 + 2], acc[bi][bj][rg * 4 + 3]));
+                    c64::px_stage4(stg + bj * 4096, lane & 31, bi * 32 + 8 * rg + 4 * g,
+                                   make_uint2(pack_bf16x2(acc[bi][bj][rg * 4], acc[bi][bj][rg * 4 + 1]), pack_bf16x2(acc[bi][bj][rg * 4 + 2], acc[bi][bj][rg * 4 + 3])));
+            const int p0 = jb + bj * 32;
+            c64::px_write_rows(stg + bj * 4096, lane, [&](int px) {
+                const int pix = p0 + px;
+                const int b = pix / HW, rem = pix % HW, y = rem / Wi, x = rem % Wi;
+                const int h = y / P, p = y % P, w = x / P, q = x % P;
+                return out + (((size_t)b * Hp + h) * Wp + w) * (size_t)(P * P * CV_C) + (size_t)(p * P + q) * CV_C;
+            });
         }
     }
 };

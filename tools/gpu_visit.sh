@@ -78,6 +78,10 @@ for s in "$@"; do
     r6gemm)    timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -s -x -k "gemm256 or linear or vit_large or small_painter" > gpurun_out/r6gemm.log 2>&1; echo "r6gemm rc=$?"; grep -a "passed\|failed\|rror\|worst" gpurun_out/r6gemm.log | tail -12 ;;
     mixedab)   timeout 600 python tools/step_knob_ab.py 4 6 "full rounds + half tiles (round 6):12=0" "uniform tiles (round 5):12=1" > gpurun_out/mixedab.log 2>&1; echo "mixedab rc=$?"; tail -3 gpurun_out/mixedab.log ;;
     lntests)   timeout 300 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "layernorm" > gpurun_out/lntests.log 2>&1; echo "lntests rc=$?"; tail -2 gpurun_out/lntests.log ;;
+    conv2)     timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_model_gpu.py -m gpu -q -x -k "conv or decoder or small_painter or vit_large_b8" > gpurun_out/conv2_tests.log 2>&1; echo "conv2 tests rc=$?"; tail -2 gpurun_out/conv2_tests.log
+               timeout 300 python tools/conv_bench.py > gpurun_out/conv2_bench.log 2>&1; echo "bench rc=$?"; grep -v amdgpu.ids gpurun_out/conv2_bench.log ;;
+    convab)    for l in libpainter_hip_prev.so libpainter_hip.so; do echo "== $l"; PAINTER_AMD_LIB=painter_amd/lib/$l timeout 300 python tools/conv_bench.py 2>&1 | grep -v amdgpu.ids; done > gpurun_out/convab_bench.log 2>&1; cat gpurun_out/convab_bench.log
+               timeout 900 python tools/step_lib_ab.py 3 6 "conv epilogues stored as whole pixel rows through LDS (+ weights two taps ahead)=painter_amd/lib/libpainter_hip.so" "committed=painter_amd/lib/libpainter_hip_prev.so" > gpurun_out/convab.log 2>&1; echo "convab rc=$?"; tail -3 gpurun_out/convab.log ;;
     mixedprobe) timeout 300 python tools/gemm_mixed_probe.py > gpurun_out/mixedprobe.log 2>&1; echo "mixedprobe rc=$?"; cat gpurun_out/mixedprobe.log ;;
     lnfwdab)   timeout 600 python tools/step_knob_ab.py 4 6 "LN forward, persistent waves (round 6):13=1" "one row per wave (round 5):13=0" > gpurun_out/lnfwdab.log 2>&1; echo "lnfwdab rc=$?"; tail -3 gpurun_out/lnfwdab.log ;;
     deltaprobe) timeout 300 python tools/attn_delta_probe.py > gpurun_out/deltaprobe.log 2>&1; echo "deltaprobe rc=$?"; cat gpurun_out/deltaprobe.log ;;
