@@ -82,6 +82,16 @@ for s in "$@"; do
                timeout 300 python tools/conv_bench.py > gpurun_out/conv2_bench.log 2>&1; echo "bench rc=$?"; grep -v amdgpu.ids gpurun_out/conv2_bench.log ;;
     convab)    for l in libpainter_hip_prev.so libpainter_hip.so; do echo "== $l"; PAINTER_AMD_LIB=painter_amd/lib/$l timeout 300 python tools/conv_bench.py 2>&1 | grep -v amdgpu.ids; done > gpurun_out/convab_bench.log 2>&1; cat gpurun_out/convab_bench.log
                timeout 900 python tools/step_lib_ab.py 3 6 "conv epilogues stored as whole pixel rows through LDS (+ weights two taps ahead)=painter_amd/lib/libpainter_hip.so" "committed=painter_amd/lib/libpainter_hip_prev.so" > gpurun_out/convab.log 2>&1; echo "convab rc=$?"; tail -3 gpurun_out/convab.log ;;
+    patchsweep) for pt in 0 605 606 608 1204; do
+                 (cd /tmp && for c in "FETCH_SIZE" "WRITE_SIZE"; do
+                    PA_G256_PATCH=$pt PAINTER_AMD_SIDE_STREAM=0 timeout 100 rocprofv3 --kernel-trace --output-format csv --pmc $c -d $OLDPWD/gpurun_out/pmc_$c -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-optimizer --no-reference-gpu --no-secondary --profile-steps 0 --min-seconds 0 > $OLDPWD/gpurun_out/pmc_$c.log 2>&1; done)
+                 python tools/pmc_traffic.py gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE gpurun_out/traffic_patch_$pt.json > /dev/null 2>&1
+                 rm -rf gpurun_out/pmc_FETCH_SIZE gpurun_out/pmc_WRITE_SIZE
+                 python -c "import json,sys; t=json.load(open('gpurun_out/traffic_patch_$pt.json')); print('patch', '$pt', {k: (v['hbm_read_bytes'] // 1000000, v['hbm_write_bytes'] // 1000000) for k, v in t.items() if not k.startswith('_')})"
+               done 2>&1 | tee gpurun_out/patchsweep.log
+               timeout 500 python tools/step_knob_ab.py 3 6 "patch 4 x 8 (shipped):11=0" "patch 6 x 5:11=605" "patch 6 x 6:11=606" > gpurun_out/patchab.log 2>&1; tail -4 gpurun_out/patchab.log ;;
+    stepbounds) timeout 600 python tools/step_bounds.py > gpurun_out/stepbounds.log 2>&1; echo "stepbounds rc=$?"; grep -v amdgpu.ids gpurun_out/stepbounds.log ;;
+    layoutprobe) timeout 300 python tools/gemm_layout_probe.py > gpurun_out/layoutprobe.log 2>&1; echo "layoutprobe rc=$?"; grep -v amdgpu.ids gpurun_out/layoutprobe.log ;;
     mixedprobe) timeout 300 python tools/gemm_mixed_probe.py > gpurun_out/mixedprobe.log 2>&1; echo "mixedprobe rc=$?"; cat gpurun_out/mixedprobe.log ;;
     lnfwdab)   timeout 600 python tools/step_knob_ab.py 4 6 "LN forward, persistent waves (round 6):13=1" "one row per wave (round 5):13=0" > gpurun_out/lnfwdab.log 2>&1; echo "lnfwdab rc=$?"; tail -3 gpurun_out/lnfwdab.log ;;
     deltaprobe) timeout 300 python tools/attn_delta_probe.py > gpurun_out/deltaprobe.log 2>&1; echo "deltaprobe rc=$?"; cat gpurun_out/deltaprobe.log ;;
