@@ -859,10 +859,20 @@ def main():
                 out["reference_gpu"] = rg
                 if "value" in rg:
                     out["vs_reference_gpu"] = round(out["value"] / rg["value"], 2)
-        print(json.dumps(out), flush=True)
+    else:
+        out = None
     if distributed:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+    if distributed:
+        # RCCL writes a version banner ("RCCL version : ... Librccl path : ...") to stdout when the library is torn down at interpreter exit:
+        # it would FOLLOW the JSON line.  The line is the last thing this process means to say: flush and leave without running the
+        # library's exit handlers (every collective has completed behind the barrier above; the process group is destroyed).
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(3 if (launch_check is not None and launch_check.get("mismatch")) else 0)
     if launch_check is not None and launch_check.get("mismatch"):
         raise SystemExit(3)
 

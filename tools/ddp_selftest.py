@@ -38,6 +38,10 @@ def main():
     coarse_bad = [n for n in gd if not torch.equal(gd[n], gb[n])]
     print("coarse arrangement: mismatching", len(coarse_bad), coarse_bad[:8], "collective launches", m.grad_sync.launches, flush=True)
     assert not coarse_bad and ld == lb
+    ge, le = grads(parallel.GradSync(mode="rs_ag"))         # round 6: every message as reduce_scatter_tensor + all_gather_into_tensor (AVG on RCCL)
+    rs_bad = [n for n in ge if not torch.equal(ge[n], gb[n])]
+    print("rs_ag arrangement: mismatching", len(rs_bad), rs_bad[:8], "collective launches", m.grad_sync.launches, flush=True)
+    assert not rs_bad and le == lb
     bad = [n for n in ga if not torch.equal(ga[n], gb[n])]
     nondet = [n for n in gb if not torch.equal(gb[n], gc[n])]
     worst = max([float((ga[n] - gb[n]).abs().max() / gb[n].abs().max().clamp_min(1e-30)) for n in bad] + [0.0])

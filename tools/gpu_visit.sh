@@ -92,6 +92,8 @@ for s in "$@"; do
                timeout 500 python tools/step_knob_ab.py 3 6 "patch 4 x 8 (shipped):11=0" "patch 6 x 5:11=605" "patch 6 x 6:11=606" > gpurun_out/patchab.log 2>&1; tail -4 gpurun_out/patchab.log ;;
     stepbounds) timeout 600 python tools/step_bounds.py > gpurun_out/stepbounds.log 2>&1; echo "stepbounds rc=$?"; grep -v amdgpu.ids gpurun_out/stepbounds.log ;;
     layoutprobe) timeout 300 python tools/gemm_layout_probe.py > gpurun_out/layoutprobe.log 2>&1; echo "layoutprobe rc=$?"; grep -v amdgpu.ids gpurun_out/layoutprobe.log ;;
+    benchselftest) PAINTER_AMD_DDP_SELFTEST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29551 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout 400 python bench.py --gpus 1 --steps 3 --warmup 1 --no-cpu-baseline --no-optimizer --no-reference-gpu --no-secondary --min-seconds 1 > gpurun_out/benchselftest.json 2> gpurun_out/benchselftest.err; echo "benchselftest rc=$?"; python -c "import json; ls_ = open('gpurun_out/benchselftest.json').read().strip().splitlines(); print('stdout lines', len(ls_), 'last is json', ls_[-1].startswith('{')); d = json.loads(ls_[-1]); print(d['value'], d['config']['rccl_ranks'], d['config']['grad_allreduce'][:40]); print(json.dumps(d['extra'], indent=0)[:1800])"; tail -3 gpurun_out/benchselftest.err ;;
+    multitest) timeout 900 python -m pytest tests/test_parallel_gpu.py tests/test_model_gpu.py -m gpu -q -x -k "bench_multi or selftest or ddp" > gpurun_out/multitest.log 2>&1; echo "multitest rc=$?"; tail -3 gpurun_out/multitest.log ;;
     mixedprobe) timeout 300 python tools/gemm_mixed_probe.py > gpurun_out/mixedprobe.log 2>&1; echo "mixedprobe rc=$?"; cat gpurun_out/mixedprobe.log ;;
     lnfwdab)   timeout 600 python tools/step_knob_ab.py 4 6 "LN forward, persistent waves (round 6):13=1" "one row per wave (round 5):13=0" > gpurun_out/lnfwdab.log 2>&1; echo "lnfwdab rc=$?"; tail -3 gpurun_out/lnfwdab.log ;;
     deltaprobe) timeout 300 python tools/attn_delta_probe.py > gpurun_out/deltaprobe.log 2>&1; echo "deltaprobe rc=$?"; cat gpurun_out/deltaprobe.log ;;
