@@ -45,7 +45,19 @@ def main():
         dyw, xw = torch.randn(K, rows, device="cuda").to(T), torch.randn(K, cols, device="cuda").to(T)     # wgrad: dW [rows, cols] = dY^T . X
         res = (("KK forward", timeit(lambda: ops.linear_fwd(x, w, b, EPI_BIAS))), ("KM data gradient", timeit(lambda: ops.linear_dgrad(x, wd))),
                ("MM weight gradient", timeit(lambda: ops.linear_wgrad(dyw, xw))))
+        # shader clock / board power while the forward launch loops for ~3 s (amdgpu hwmon, 100 ms: bench.py's sampler)
+        import bench
+        import time
+        smp = bench.ClockPowerSampler()
+        smp.start()
+        t0 = time.time()
+        while time.time() - t0 < 3.0:
+            for _ in range(50):
+                ops.linear_fwd(x, w, b, EPI_BIAS)
+            torch.cuda.synchronize()
+        cp = smp.stop()
         print("%d x %d output = %d tiles, K = %d (%d contraction tiles)" % (rows, cols, tiles, K, K // 64))
+        print("  looping the forward launch: %s" % (cp,))
         for name, us in res:
             print("  %-20s %8.1f us   %6.3f us per contraction tile   %6.0f TFLOP/s" % (name, us, us / (K // 64), 2.0 * rows * cols * K / us / 1e6), flush=True)
         del x, w, wd, dyw, xw
