@@ -176,7 +176,7 @@ def _algorithmic_bytes():
     qkv = BH * L * hd * 2                                        # one of q / k / v, all heads: 25.7 MB
     tables = BH * (L // 32) * 6144                               # per-query bias tables of generation 3: 38.5 MB
     return {
-        "fc1": {"bytes": R * D * 2 + Hd * D * 2 + 2 * R * Hd * 2, "what": "X [R, D] + W [4D, D] in; act + gelu' [R, 4D] out"},
+        "fc1": {"bytes": R * D * 2 + Hd * D * 2 + R * Hd * 2 + R * Hd, "what": "X [R, D] + W [4D, D] in; act bf16 + gelu' 8-bit code [R, 4D] out"},
         "wgrad": {"bytes": R * Hd * 2 + R * D * 2 + 4 * Hd * D, "what": "fc1 / fc2 weight gradient: dY [R, 4D] + X [R, D] in; dW fp32 [4D, D] out (split-K slabs and their reduction are overhead, not algorithm)"},
         # the PMC family is keyed by kernel + grid: the three data gradients with a [R, D] output (qkv: K = 3D, proj: K = D, fc1: K = 4D), one of
         # each per block -- the measured figure is their average, so is this one (round 5; the proj-only figure made the ratio look like 2.6)

@@ -37,8 +37,8 @@ enum {
 };
 
 /* Bumped whenever an entry point's argument list changes (2: `tables` in pa_attn_fwd / pa_attn_bwd; 3: `head_dim` in the attention and
- * rel-pos entry points; 4: `dxT_colsum` in pa_layernorm_bwd, `relpos_part` in pa_attn_bwd, `dx_colsum` in pa_linear_dgrad; 5: the bf16 GELU side output is gelu'(pre), pa_debug_set(9) is a test knob of the conv3x3 weight gradient, pa_attn4_trace is gone, pa_attn_bwd takes `out` / `ldo`, pa_debug_get / pa_attn_launch_counts are new).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
-#define PA_ABI_VERSION 5
+ * rel-pos entry points; 4: `dxT_colsum` in pa_layernorm_bwd, `relpos_part` in pa_attn_bwd, `dx_colsum` in pa_linear_dgrad; 5: the bf16 GELU side output is gelu'(pre), pa_debug_set(9) is a test knob of the conv3x3 weight gradient, pa_attn4_trace is gone, pa_attn_bwd takes `out` / `ldo`, pa_debug_get / pa_attn_launch_counts are new; 6: the bf16 GELU side output is an 8-bit code (uint8, row pitch ldo bytes), pa_debug_set knobs 10 .. 15).  painter_amd/_lib.py refuses a library whose pa_abi_version() differs from the header it parsed. */
+#define PA_ABI_VERSION 6
 int pa_abi_version(void);
 /* diagnostics only (tools/): which = 0 start-up stagger of alternate workgroup rows of the 256x256 GEMM in shader cycles,
  * 1 drop that kernel's epilogue stores (never set by the product path); 2 = tile order of that kernel: 0 blocked 4 x 8 patches per XCD and, for
@@ -55,10 +55,13 @@ int pa_debug_set(int which, int value);
 int pa_debug_get(int which);      /* the value last set (-1: no such knob) -- callers that change a knob temporarily restore what they found */
 
 /* ---- nn.Linear: y = x W^T + b.  models_painter.py:76 (qkv), :87 (proj), timm Mlp fc1/fc2 (:201,:230) ----
- * PA_EPI_BIAS_GELU: out = gelu(pre), pre = x W^T + b rounded to T; out2 (optional, T [M,N] ld=ldo) receives what the backward needs of
- * pre, to be handed to pa_linear_dgrad as `gelu_aux`: pre itself for PA_F32 (erf-GELU' is evaluated on it there, to fp32 accuracy), the
- * DERIVATIVE gelu'(pre) = Phi(pre) + pre phi(pre) rounded to bf16 for PA_BF16 (ABI 5: the forward epilogue has both factors in
- * registers, and the fc2 data gradient's epilogue becomes one load and one multiply instead of an erf evaluation). */
+ * PA_EPI_BIAS_GELU: out = gelu(pre), pre = x W^T + b rounded to T; out2 (optional) receives what the backward needs of pre, to be handed
+ * to pa_linear_dgrad as `gelu_aux`:
+ *   PA_F32 : pre itself, f32 [M,N] ld = ldo (erf-GELU' is evaluated on it there, to fp32 accuracy);
+ *   PA_BF16: the DERIVATIVE gelu'(pre) = Phi(pre) + pre phi(pre) (ABI 5: the forward epilogue has both factors in registers, and the fc2 data
+ *            gradient's epilogue becomes one load and one multiply) -- since ABI 6 as an 8-BIT CODE, uint8 [M,N] with a row pitch of ldo BYTES:
+ *            q = round((g' + 0.13) * 255 / 1.26), g' = q * 1.26 / 255 - 0.13 (g' lies in [-0.129, 1.129]; absolute error <= 2.5e-3).  Half the
+ *            bytes of the bf16 form on the fc1 write and on the fc2 data-gradient read; parity measured unchanged. */
 int pa_linear_fwd(int dtype, int epilogue, const void* x /*T [M,K]*/, int64_t ldx, const void* w /*T [N,K]*/,
                   const float* bias /*[N]*/, void* out, void* out2, int64_t ldo, const float* resid /*f32 [M,N] ld=ldo*/,
                   const float* rowscale /*[M/rows_per_sample] or NULL*/, int rows_per_sample, int M, int N, int K,
@@ -72,7 +75,7 @@ int pa_linear_pixshuf(int dtype, const void* x, int64_t ldx, const void* w /*T [
  * pass over dX. */
 int64_t pa_linear_dgrad_workspace_bytes(int M, int K);
 int pa_linear_dgrad(int dtype, const void* dy /*T [M,N]*/, int64_t lddy, const void* w /*T [N,K]*/,
-                    const void* gelu_aux /*T [M,K] ld=lddx or NULL*/, void* dx /*T [M,K]*/, int64_t lddx, float* dx_colsum,
+                    const void* gelu_aux /*NULL, or what pa_linear_fwd(PA_EPI_BIAS_GELU) put into out2: f32 [M,K] ld=lddx | uint8 [M,K] pitch lddx bytes*/, void* dx /*T [M,K]*/, int64_t lddx, float* dx_colsum,
                     void* workspace, int M, int N, int K, hipStream_t stream);
 int64_t pa_linear_wgrad_workspace_bytes(int dtype, int M, int N, int K);
 int pa_linear_wgrad(int dtype, const void* dy /*T [M,N]*/, int64_t lddy, const void* x /*T [M,K]*/, int64_t ldx,

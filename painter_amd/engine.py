@@ -7,7 +7,7 @@ Backward is written by hand -- nothing is delegated to to
 
 Data layout in HBM (per rank):
   residual stream x        fp32 [B'*L, D]           B' = 2B for blocks 0..merge_idx, B afterwards
-  GEMM operands / acts     T    (bf16 or fp32)      ln out [R,D], qkv [R,3D], attn out [R,D], fc1 act + gelu aux [R,4D]
+  GEMM operands / acts     T    (bf16 or fp32)      ln out [R,D], qkv [R,3D], attn out [R,D], fc1 act [R,4D] (+ gelu aux: fp32 pre-activation, or the 8-bit gelu' code)
   tap concat               T    [B*L, 4D]           LayerNorm of the 4 taps written straight into column slices
   decoder image            T    NHWC [B, H, W, 64]  pixel shuffle fused into decoder_embed's epilogue
   pred / loss              fp32 NCHW [B,3,H,W], [2]

@@ -60,13 +60,32 @@ def linear_fwd(x, w, bias, epilogue=EPI_BIAS, out=None, out2=None, resid=None, r
 
 def linear_gelu(x, w, bias, need_aux=True):
     """-> (act = gelu(x W^T + b), aux): aux is what linear_dgrad(gelu_aux=...) needs of the pre-activation -- the pre-activation itself in the
-    exact-fp32 build, gelu'(pre) rounded to bf16 in the bf16 build (include/painter_hip.h, PA_EPI_BIAS_GELU)."""
+    exact-fp32 build, the 8-bit code of gelu'(pre) (uint8 [M, N]; gelu_aux_decode) in the bf16 build (include/painter_hip.h, PA_EPI_BIAS_GELU)."""
     M = x.shape[0]
     N = w.shape[0]
     act = torch.empty((M, N), dtype=x.dtype, device=x.device)
-    aux = torch.empty((M, N), dtype=x.dtype, device=x.device) if need_aux else None
+    aux = torch.empty((M, N), dtype=gelu_aux_dtype(x.dtype), device=x.device) if need_aux else None
+    assert aux is None or aux.stride(0) == act.stride(0)
     linear_fwd(x, w, bias, EPI_BIAS_GELU, out=act, out2=aux)
     return act, aux
+
+
+G8_OFF, G8_RANGE = 0.13, 1.26
+
+
+def gelu_aux_dtype(T):
+    """dtype of linear_gelu's second result: the pre-activation (fp32 build), or the 8-bit code of gelu'(pre) (bf16 build, C ABI 6)."""
+    return torch.float32 if T == torch.float32 else torch.uint8
+
+
+def gelu_aux_decode(aux):
+    """uint8 code -> gelu' (float32), as the fc2 data-gradient epilogue decodes it (include/painter_hip.h, PA_EPI_BIAS_GELU); tests / tools."""
+    return aux.to(torch.float32) * (G8_RANGE / 255.0) - G8_OFF
+
+
+def gelu_aux_encode(g):
+    """gelu' values -> uint8 code (tests / tools)."""
+    return torch.clamp(torch.floor((g.double() + G8_OFF) * (255.0 / G8_RANGE) + 0.5), 0, 255).to(torch.uint8)
 
 
 def linear_pixshuf(x, w, bias, batch, Hp, Wp, P, C):
@@ -87,8 +106,8 @@ def linear_dgrad(dy, w, gelu_aux=None, out=None, colsum_out=None):
     _req(dy); _req(w, T)
     if out is None:
         out = torch.empty((M, K), dtype=T, device=dy.device)
-    if gelu_aux is not None:
-        assert gelu_aux.stride(0) == out.stride(0) and gelu_aux.dtype == T
+    if gelu_aux is not None:      # (fp32: the pre-activation, ld in elements; bf16: the uint8 code, row pitch in bytes -- the same number either way)
+        assert gelu_aux.stride(0) == out.stride(0) and gelu_aux.dtype == gelu_aux_dtype(T), (gelu_aux.dtype, gelu_aux.stride(0), out.stride(0))
     ws = None
     if colsum_out is not None:
         assert colsum_out.shape == (K,) and colsum_out.dtype == torch.float32 and colsum_out.is_contiguous()

@@ -19,7 +19,7 @@ def main():
     M = 12544
     x1, w = rnd(M, 1024), rnd(4096, 1024) * 0.05
     b = rnd(4096).float()
-    a, pre = torch.empty(M, 4096, dtype=T, device=DEV), torch.empty(M, 4096, dtype=T, device=DEV)
+    a, pre = torch.empty(M, 4096, dtype=T, device=DEV), torch.empty(M, 4096, dtype=torch.uint8, device=DEV)      # (second output: the 8-bit gelu' code, C ABI 6)
     cases = [("bias, one store", lambda: ops.linear_fwd(x1, w, b, EPI_BIAS, out=a)),
              ("bias + GELU, one store", lambda: ops.linear_fwd(x1, w, b, EPI_BIAS_GELU, out=a, out2=None)),
              ("bias + GELU, two stores", lambda: ops.linear_fwd(x1, w, b, EPI_BIAS_GELU, out=a, out2=pre))]
