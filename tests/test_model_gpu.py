@@ -47,7 +47,8 @@ def build(cfg, seed, dtype, train=False):
 # 6.3e-2).  So the error of the rel-pos table gradients -- the noisiest tensors of the model: class sums of dS = P o (dP - Delta), whose rows
 # sum to zero, under a 2^-9 rounding of every P, dS and bias-table entry -- is a property of bf16 arithmetic on this model that the
 # reference shows to the same degree, not a loose kernel.  The head_dim-80 small model has short tensors (few samples per tensor, larger
-# spread: 4.0e-2 .. 6.3e-2 measured) and no yardstick of its own: 1e-1 there.
+# spread: 4.0e-2 .. 6.3e-2 measured); its yardstick is taken LIVE by tests/test_live_yardstick_gpu.py (the reference's own bf16 autocast on the same
+# cases: 3.0e-2 .. 7.3e-2, the HIP build at 0.55 - 0.80 x of it); the fixture tests keep the reference's own worst, 7.3e-2 (round 5: 1e-1).
 BF16_SAMPLE_GATE = 2.45e-2         # every tensor except the rel-pos tables, ViT-L fixtures: 1.25 x the reference's own 1.95e-2 (round 6; 1.5 x before)
 # Round 6 ("find what blocks.0.attn.qkv.weight loses").  Nothing: the sampled rel-max is the MAXIMUM over ~3000 samples
 # of one tensor, a heavy-tailed estimator -- per block and weight family (tools/grad_yardstick.py, profiles/r06_grad_yardstick_per_block.log) the HIP
@@ -57,7 +58,7 @@ BF16_SAMPLE_GATE = 2.45e-2         # every tensor except the rel-pos tables, ViT
 # chance.  So the gate that can see a systematic loss is a Frobenius one: over the stored samples of each of the blocks' 96 weight matrices,
 # at 1.0 x the reference's own worst matrix.
 BF16_SAMPLE_FRO_GATE = 1.3e-2      # ViT-L fixtures: relative Frobenius error over the samples of a tensor (reference's own worst matrix: 1.28e-2; HIP: 1.12e-2)
-BF16_SAMPLE_GATE_SHORT = 1.0e-1    # the head_dim-80 small models
+BF16_SAMPLE_GATE_SHORT = 7.3e-2    # the head_dim-80 small models: the reference's own bf16-autocast deviation on them
 BF16_RELPOS_FRO_GATE = 5.0e-2      # rel-pos tables: relative Frobenius error over the full tensor (reference's own: 4.17e-2)
 BF16_RELPOS_GATE = 1.9e-1          # rel-pos tables: sampled rel-max, 1.5 x the reference's own 1.28e-1
 

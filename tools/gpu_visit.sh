@@ -96,6 +96,7 @@ for s in "$@"; do
     multitest) timeout 900 python -m pytest tests/test_parallel_gpu.py tests/test_model_gpu.py -m gpu -q -x -k "bench_multi or selftest or ddp" > gpurun_out/multitest.log 2>&1; echo "multitest rc=$?"; tail -3 gpurun_out/multitest.log ;;
     mixedprobe) timeout 300 python tools/gemm_mixed_probe.py > gpurun_out/mixedprobe.log 2>&1; echo "mixedprobe rc=$?"; cat gpurun_out/mixedprobe.log ;;
     lnfwdab)   timeout 600 python tools/step_knob_ab.py 4 6 "LN forward, persistent waves (round 6):13=1" "one row per wave (round 5):13=0" > gpurun_out/lnfwdab.log 2>&1; echo "lnfwdab rc=$?"; tail -3 gpurun_out/lnfwdab.log ;;
+    livey)     timeout 1200 python -m pytest tests/test_live_yardstick_gpu.py tests/test_model_gpu.py -m gpu -q -s -k "live_yardstick or h14" > gpurun_out/livey.log 2>&1; echo "livey rc=$?"; grep -v amdgpu.ids gpurun_out/livey.log | grep "head_dim 80\|h14.*bf16\|train_one_epoch at\|passed\|failed\|Error\|assert" | cut -c1-1500 ;;
     deltaprobe) timeout 300 python tools/attn_delta_probe.py > gpurun_out/deltaprobe.log 2>&1; echo "deltaprobe rc=$?"; cat gpurun_out/deltaprobe.log ;;
     *)         echo "unknown section $s" ;;
   esac
