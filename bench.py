@@ -227,7 +227,7 @@ def secondary_seggpt_n32(dev, replays=5):
     t = (time.perf_counter() - t0) / replays
     res = {"value": round(N / t, 2), "unit": "images/sec", "ms_per_forward": round(t * 1e3, 3), "prompts": N, "dtype": "bf16",
            "tflops": round(N * 1.5897 / t, 1), "frac_whole_model": round(N * 1.5897 / t / PEAK_BF16_TFLOPS, 4),
-           "replay_equals_eager": bool(torch.equal(g_pred, ref_pred)), "loss": round(float(loss), 6),
+           "replay_equals_eager": bool(torch.equal(g_pred, ref_pred)), "loss": round(float(loss.detach()), 6),
            "workload": "seggpt_vit_large_patch16_input896x448 inference, batch=32 in-context prompts, 1xMI355X, forward-only hipGraph replay x%d (BASELINE configs[3])" % replays}
     del graph, m
     torch.cuda.empty_cache()
@@ -260,7 +260,7 @@ def secondary_vit_huge(dev, steps=3, batch=4):
     ips = batch / t
     res = {"value": round(ips, 2), "unit": "images/sec", "ms_per_step": round(t * 1e3, 2), "batch": batch, "steps": steps, "dtype": "bf16",
            "frac": round(ips * spec["blocks"] / 1e12 / PEAK_BF16_TFLOPS, 4), "whole_model_frac": round(ips * spec["whole"] / 1e12 / PEAK_BF16_TFLOPS, 4),
-           "loss": round(float(loss), 6), "workload": spec["workload"] % ("bf16", batch, 1)}
+           "loss": round(float(loss.detach()), 6), "workload": spec["workload"] % ("bf16", batch, 1)}
     del m
     torch.cuda.empty_cache()
     return res

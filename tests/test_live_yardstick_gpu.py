@@ -96,7 +96,7 @@ def test_head_dim_80_bf16_build_within_the_reference_own_bf16_deviation(which, b
     gh = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
     ref, hip = _deviation(g16, g32), _deviation(gh, g32)
     pr, ph = G.rel_fro(p16, p32), G.rel_fro(pred.detach().float().cpu(), p32)
-    lr, lh = abs(l16 - l32) / abs(l32), abs(float(loss) - l32) / abs(l32)
+    lr, lh = abs(l16 - l32) / abs(l32), abs(float(loss.detach()) - l32) / abs(l32)
     print("head_dim 80 (%s): reference bf16 autocast | HIP bf16, both against the reference's fp32 run: loss %.2e | %.2e, pred rel-Frobenius %.2e | %.2e; "
           % (which, lr, lh, pr, ph) + "; ".join("%s %.3e (%s) | %.3e (%s)" % ((k,) + ref[k] + hip[k]) for k in ref))
     assert ph <= FACTOR_FRO * pr, (ph, pr)

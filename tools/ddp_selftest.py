@@ -29,7 +29,7 @@ def main():
         loss, _, _ = m(inp[0], inp[1], bool_masked_pos=inp[2], valid=inp[3])
         loss.backward()
         torch.cuda.synchronize()
-        return {n: p.grad.clone() for n, p in m.named_parameters()}, float(loss)
+        return {n: p.grad.clone() for n, p in m.named_parameters()}, float(loss.detach())
 
     ga, la = grads(parallel.GradSync())
     gb, lb = grads(None)

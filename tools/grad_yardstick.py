@@ -136,7 +136,7 @@ def main():
     torch.cuda.synchronize()
     gh = {n: p.grad.detach().float().cpu() for n, p in m.named_parameters()}
     d = deviation(gh, g32)
-    d["loss_rel"] = abs(float(loss) - l32) / abs(l32)
+    d["loss_rel"] = abs(float(loss.detach()) - l32) / abs(l32)
     d["pred_rel_frobenius"] = G.rel_fro(pred.detach().float().cpu(), p32)
     d["pred_rel_max"] = G.rel_err(pred.detach().float().cpu(), p32)
     d["per_block"] = per_block(gh, g32, cfg.depth)
