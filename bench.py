@@ -247,6 +247,7 @@ def secondary_vit_huge(dev, steps=3, batch=4):
     def step():
         for p in m.parameters():
             p.grad = None
+        m._hot.relpos_stale()                   # re-pack the rel-pos tables every step, as after an optimizer update
         loss, _, _ = m(imgs, tgts, bool_masked_pos=mask, valid=valid)
         loss.backward()
         return loss
@@ -608,6 +609,9 @@ def main():
     def step():
         for p in model.parameters():
             p.grad = None
+        # as in plain training, where the optimizer has just rewritten the rel-pos tables: every step re-packs them (one launch for all
+        # blocks); the bf16 weight copies stay -- painter_amd.optim.AdamW rewrites those inside its own pass, outside forward + backward
+        model._hot.relpos_stale()
         loss, _, _ = net[0](imgs, tgts, bool_masked_pos=mask, valid=valid)
         loss.backward()
         return loss

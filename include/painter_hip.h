@@ -110,6 +110,10 @@ int pa_relpos_rows_padded(int Hp, int Wp);
  * rcat: T [pa_relpos_rows_padded, hd] = [rel_pos_h ; rel_pos_w ; 0] */
 int pa_relpos_pack(int dtype, const float* rel_pos_h, const float* rel_pos_w, void* rcat, int Hp, int Wp, int head_dim,
                    hipStream_t stream);
+/* Every block's Rcat and Rcat^T (pa_relpos_pack_t below) in ONE launch: tabs = device array of 2 * nblocks `const float*` -- rel_pos_h of
+ * every block, then rel_pos_w of every block (util/vitdet_utils.py:63-125 reads these per block); rcat: T [nblocks, NRP, hd]; rcatT: T
+ * [nblocks, hd, NRP].  Values identical to the per-block entry points; what a training step calls after the optimizer has written the tables. */
+int pa_relpos_pack_batch(int dtype, const void* tabs, void* rcat, void* rcatT, int nblocks, int Hp, int Wp, int head_dim, hipStream_t stream);
 /* qkv: T [batch*L, 3*heads*hd] as produced by the qkv Linear; out: T [batch*L, heads*hd]; lse: f32 [batch*heads, L].
  * tables: NULL (inference), or pa_attn_tables_bytes() of device memory that receives the per-query bias tables the
  * backward reuses (only the 28-token-wide bf16 kernels write it; the size is 0 for every other case). */

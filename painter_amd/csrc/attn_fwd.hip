@@ -197,6 +197,35 @@ extern "C" int pa_relpos_pack(int dtype, const float* rel_pos_h, const float* re
     LAUNCH_CHECK();
 }
 
+// Rcat and Rcat^T of EVERY block in one launch (round 6): blockIdx.y = block, blockIdx.z = 0 -> rcat [nblocks][NRP][hd], 1 -> rcatT [nblocks][hd][NRP].
+// `tabs`: device array of 2 * nblocks pointers, rel_pos_h of every block, then rel_pos_w of every block.  Same values as the two per-block
+// kernels (pa_relpos_pack / pa_relpos_pack_t), bit for bit; a training step re-packs all blocks with one launch instead of 2 per block.
+template <typename T> __global__ void relpos_pack_batch_kernel(const float* const* __restrict__ tabs, int nblocks, int nh, int nw, T* __restrict__ rcat,
+                                                               T* __restrict__ rcatT, int NRP, int hd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= NRP * hd) return;
+    const int blk = blockIdx.y;
+    const bool tr = blockIdx.z != 0;
+    const int r = tr ? i % NRP : i / hd, d = tr ? i / NRP : i % hd;
+    const float* rh = tabs[blk];
+    const float* rw = tabs[nblocks + blk];
+    float v = 0.f;
+    if (r < nh) v = rh[r * hd + d];
+    else if (r - nh < nw) v = rw[(r - nh) * hd + d];
+    (tr ? rcatT : rcat)[(size_t)blk * NRP * hd + i] = from_f<T>(v);
+}
+extern "C" int pa_relpos_pack_batch(int dtype, const void* tabs, void* rcat, void* rcatT, int nblocks, int Hp, int Wp, int head_dim, hipStream_t st) {
+    if (head_dim <= 0 || head_dim % 16 || nblocks <= 0 || nblocks > 65535) return (int)hipErrorInvalidValue;
+    const int NRP = pa_relpos_rows_padded(Hp, Wp);
+    const int n = NRP * head_dim;
+    const float* const* t = reinterpret_cast<const float* const*>(tabs);
+    if (dtype == PA_BF16)
+        PA_LAUNCH(relpos_pack_batch_kernel<bf16>, dim3((n + 255) / 256, nblocks, 2), dim3(256), 0, st, t, nblocks, 2 * Hp - 1, 2 * Wp - 1, (bf16*)rcat, (bf16*)rcatT, NRP, head_dim);
+    else
+        PA_LAUNCH(relpos_pack_batch_kernel<float>, dim3((n + 255) / 256, nblocks, 2), dim3(256), 0, st, t, nblocks, 2 * Hp - 1, 2 * Wp - 1, (float*)rcat, (float*)rcatT, NRP, head_dim);
+    LAUNCH_CHECK();
+}
+
 static int attn_tab_stride(int Hp, int Wp, int hd, int elem) {
     int a = 32 * (Hp + Wp) * 4, b = 32 * hd * elem;
     int s = a > b ? a : b;

@@ -35,6 +35,7 @@ _ATTN_PREP = os.environ.get("PAINTER_AMD_ATTN_PREP", "fused")
 _FC1_COLSUM = os.environ.get("PAINTER_AMD_FC1_COLSUM", "epilogue")
 _SIDE_STREAM = os.environ.get("PAINTER_AMD_SIDE_STREAM", "1") != "0"
 _SIDE_PRIORITY = int(os.environ.get("PAINTER_AMD_SIDE_PRIORITY", "0"))
+_RELPOS_PACK = os.environ.get("PAINTER_AMD_RELPOS_PACK", "batch")      # "per_block": the per-block pack launches of rounds 4 - 5 (A/B only)
 _configured = False
 # sizing of the parameter-gradient kernels when they run on the side stream, beside the data-gradient chain (0 = stand-alone sizing)
 WGRAD_SIDE_TARGET = 96       # round 5 re-sweep on the lighter side stream (tools/step_knob_ab.py, profiles/r05_wgrad_side_target_sweep.log): 96 -> 53.08, 128 -> 53.42, 160 -> 54.09, 192 -> 54.47 ms/step
@@ -200,21 +201,43 @@ class HotPath:
         return ent[1]
 
     def relpos(self, pre, P, transposed):
-        """Rcat / Rcat^T operands of block `pre`, packed once per parameter version (they used to be re-packed in every forward and
-        every backward of every block: 48 tiny launches per step).  What this saves depends on the loop: the versions only stand still
-        between optimizer steps -- forward + backward timing (bench.py), evaluation, gradient-accumulation micro-steps; in plain training
-        every step re-packs (the fused AdamW refreshes the bf16 WEIGHT copies, not these).  Like every cache here it is keyed on the
-        tensor version: a write that does not bump it (p.data.copy_, an in-place collective) needs HotPath.invalidate()."""
+        """Rcat / Rcat^T operand of block `pre`.  Every block's pair is packed by ONE launch (pa_relpos_pack_batch, round 6) whenever the
+        version of the asked-for block's tables has moved -- i.e. once per optimizer step in plain training (rounds 1 - 5: one launch per
+        block and orientation, 48 per step; cached per parameter version since round 4, which only helped loops that leave the parameters
+        alone: forward + backward timing, evaluation, accumulation micro-steps).  Keyed on addresses and tensor versions like every cache
+        here: a write that bumps no version (p.data.copy_, an in-place collective) needs HotPath.invalidate()."""
         c = self.cfg
+        i = int(pre.split(".")[1])
         rh, rw = P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"]
-        key = (pre, transposed, rh.data_ptr(), rw.data_ptr())
-        ent = self._rcache.get(key)
-        ver = (rh._version, rw._version)
-        if ent is None or ent[0] != ver or ent[1].device != rh.device:
-            buf = (ops.relpos_pack_t if transposed else ops.relpos_pack)(rh, rw, c.Hp, c.Wp, self.T)
-            self._rcache[key] = (ver, buf)
-            return buf
-        return ent[1]
+        st = self._rcache
+        if _RELPOS_PACK == "per_block":            # rounds 4 - 5 (A/B: tools/step_engine_ab.py): one launch per block and orientation
+            key, ver = (pre, transposed), (rh.data_ptr(), rw.data_ptr(), rh._version, rw._version)
+            if key not in st or st[key][0] != ver:
+                st[key] = (ver, (ops.relpos_pack_t if transposed else ops.relpos_pack)(rh, rw, c.Hp, c.Wp, self.T))
+            return st[key][1]
+        if st and st["dev"] == rh.device and st["ptr"][i] == (rh.data_ptr(), rw.data_ptr()) and st["ver"][i] == (rh._version, rw._version):
+            return (st["rcatT"] if transposed else st["rcat"])[i]
+        hs = [P["blocks.%d.attn.rel_pos_h" % k] for k in range(c.depth)]
+        ws = [P["blocks.%d.attn.rel_pos_w" % k] for k in range(c.depth)]
+        hd = rh.shape[1]
+        for t in hs + ws:
+            assert t.dtype == torch.float32 and t.is_contiguous() and t.device == rh.device and t.shape[1] == hd
+        ptr = [(h.data_ptr(), w.data_ptr()) for h, w in zip(hs, ws)]
+        same = bool(st) and st["dev"] == rh.device and st["ptr"] == ptr
+        tabs = st["tabs"] if same else torch.tensor([q[0] for q in ptr] + [q[1] for q in ptr], dtype=torch.int64).to(rh.device)
+        rcat, rcatT = ops.relpos_pack_batch(tabs, c.depth, c.Hp, c.Wp, hd, self.T, rcat=st["rcat"] if same else None, rcatT=st["rcatT"] if same else None)
+        st.clear()
+        st.update(dev=rh.device, ptr=ptr, ver=[(h._version, w._version) for h, w in zip(hs, ws)], tabs=tabs, rcat=rcat, rcatT=rcatT)
+        return (rcatT if transposed else rcat)[i]
+
+    def relpos_stale(self):
+        """Mark the packed rel-pos tables stale, as an optimizer update of the tables does through their version counters (buffers and the
+        address table stay): bench.py calls it before every timed step so that forward + backward is timed as training runs it."""
+        st = self._rcache
+        if _RELPOS_PACK == "per_block":
+            st.clear()
+        elif st:
+            st["ver"] = [None] * len(st["ver"])
 
     def invalidate(self):
         """Drop every cached operand copy (bf16 weights, packed patch weight, Rcat / Rcat^T): call after writing parameters in a way

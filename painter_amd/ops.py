@@ -204,6 +204,21 @@ def relpos_pack(rel_pos_h, rel_pos_w, Hp, Wp, dtype):
     return rcat
 
 
+def relpos_pack_batch(tabs, nblocks, Hp, Wp, hd, dtype, rcat=None, rcatT=None):
+    """Every block's Rcat [nblocks, NRP, hd] and Rcat^T [nblocks, hd, NRP] in one launch.  tabs: int64 device tensor of 2 * nblocks
+    addresses (rel_pos_h of every block, then rel_pos_w of every block; fp32 [2Hp-1, hd] / [2Wp-1, hd] each)."""
+    nrp = lib.pa_relpos_rows_padded(Hp, Wp)
+    assert tabs.dtype == torch.int64 and tabs.numel() == 2 * nblocks and tabs.is_cuda and tabs.is_contiguous()
+    if rcat is None:
+        rcat = torch.empty((nblocks, nrp, hd), dtype=dtype, device=tabs.device)
+    if rcatT is None:
+        rcatT = torch.empty((nblocks, hd, nrp), dtype=dtype, device=tabs.device)
+    assert rcat.shape == (nblocks, nrp, hd) and rcatT.shape == (nblocks, hd, nrp) and rcat.is_contiguous() and rcatT.is_contiguous()
+    assert rcat.dtype == dtype and rcatT.dtype == dtype
+    check(lib.pa_relpos_pack_batch(code(dtype), p(tabs), p(rcat), p(rcatT), nblocks, Hp, Wp, hd, stream()), "pa_relpos_pack_batch")
+    return rcat, rcatT
+
+
 def attn_fwd(qkv, rcat, batch, L, heads, Hp, Wp, scale, need_tables=False):
     """qkv [batch*L, 3*heads*hd] T -> (out [batch*L, heads*hd] T, lse [batch*heads, L] f32[, tables]).
     need_tables: also return the per-query bias tables the backward reuses (None when the kernels in use do not export them)."""

@@ -387,6 +387,28 @@ def _attn_cases(shapes):
     return out
 
 
+@pytest.mark.parametrize("T", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nblocks,Hp,Wp,hd", [(24, 56, 28, 64), (3, 8, 4, 64), (5, 64, 32, 80), (1, 24, 12, 80)])
+def test_relpos_pack_batch_equals_the_per_block_packs(T, nblocks, Hp, Wp, hd):
+    """pa_relpos_pack_batch (one launch for every block's Rcat and Rcat^T, what a training step runs after the optimizer wrote the tables)
+    against pa_relpos_pack / pa_relpos_pack_t block by block: bit-identical, padding rows included; re-packing into the same buffers after
+    the tables changed sees the new values."""
+    hs = [gen((2 * Hp - 1, hd), 10 + k, 0.2) for k in range(nblocks)]
+    ws = [gen((2 * Wp - 1, hd), 50 + k, 0.2) for k in range(nblocks)]
+    tabs = torch.tensor([t.data_ptr() for t in hs] + [t.data_ptr() for t in ws], dtype=torch.int64).cuda()
+    rcat, rcatT = ops.relpos_pack_batch(tabs, nblocks, Hp, Wp, hd, T)
+    nrp = rcat.shape[1]
+    assert rcat.shape == (nblocks, nrp, hd) and rcatT.shape == (nblocks, hd, nrp) and nrp % 32 == 0 and nrp >= 2 * Hp + 2 * Wp - 2
+    for k in range(nblocks):
+        assert torch.equal(rcat[k], ops.relpos_pack(hs[k], ws[k], Hp, Wp, T)), k
+        assert torch.equal(rcatT[k], ops.relpos_pack_t(hs[k], ws[k], Hp, Wp, T)), k
+    hs[nblocks - 1].mul_(-2.0)
+    ws[0].add_(1.0)
+    ops.relpos_pack_batch(tabs, nblocks, Hp, Wp, hd, T, rcat=rcat, rcatT=rcatT)
+    for k in (0, nblocks - 1):
+        assert torch.equal(rcat[k], ops.relpos_pack(hs[k], ws[k], Hp, Wp, T)) and torch.equal(rcatT[k], ops.relpos_pack_t(hs[k], ws[k], Hp, Wp, T))
+
+
 @pytest.mark.parametrize("T,B,H,Hp,Wp,gen_", _attn_cases([(1, 2, 8, 4), (2, 2, 56, 28), (1, 1, 16, 8), (1, 2, 8, 12), (2, 1, 8, 20), (1, 2, 16, 16),
                                                           (1, 1, 8, 24), (1, 3, 16, 28), (1, 1, 8, 28)]))
 def test_attn_fwd(T, B, H, Hp, Wp, gen_, attn_generation):

@@ -29,9 +29,13 @@ def main():
     c = m._cfg
     inp = bench.synthetic_inputs(8, c.H, c.W, c.L, 1234, dev)
 
+    repack = [False]           # pseudo-global REPACK=1: drop the packed rel-pos tables before every step (= a step after an optimizer update)
+
     def step():
         for p in m.parameters():
             p.grad = None
+        if repack[0]:
+            m._hot.relpos_stale()
         loss, _, _ = m(inp[0], inp[1], bool_masked_pos=inp[2], valid=inp[3])
         loss.backward()
 
@@ -48,7 +52,7 @@ def main():
 
     for _ in range(3):
         step()
-    touched = sorted({k for _, kn in settings for k in kn})
+    touched = sorted({k for _, kn in settings for k in kn if k != "REPACK"})
     saved = {k: getattr(engine, k) for k in touched}
     res = {name: [] for name, _ in settings}
     try:
@@ -56,6 +60,8 @@ def main():
             for name, kn in settings:
                 for k in touched:
                     setattr(engine, k, kn.get(k, saved[k]))
+                repack[0] = kn.get("REPACK", "0") == "1"
+                m._hot._rcache.clear()                  # (the two pack arrangements keep different things in it)
                 res[name].append(timed())
     finally:
         for k, v in saved.items():
