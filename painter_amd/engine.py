@@ -205,7 +205,8 @@ class HotPath:
         version of the asked-for block's tables has moved -- i.e. once per optimizer step in plain training (rounds 1 - 5: one launch per
         block and orientation, 48 per step; cached per parameter version since round 4, which only helped loops that leave the parameters
         alone: forward + backward timing, evaluation, accumulation micro-steps).  Keyed on addresses and tensor versions like every cache
-        here: a write that bumps no version (p.data.copy_, an in-place collective) needs HotPath.invalidate()."""
+        here: a write that bumps no version (p.data.copy_, an in-place collective) needs HotPath.invalidate().  The first call (and any call after
+        the tables moved in memory) uploads the 2 * depth addresses: run one eager forward before capturing a hipGraph, as every caller here does."""
         c = self.cfg
         i = int(pre.split(".")[1])
         rh, rw = P[pre + "attn.rel_pos_h"], P[pre + "attn.rel_pos_w"]
